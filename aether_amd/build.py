@@ -1,0 +1,60 @@
+"""Builds libaether_hip.so (the gfx950 kernels + C ABI) in-tree with hipcc.
+
+The shared object is written next to the sources (aether_amd/csrc/libaether_hip.so) so that it travels
+to the GPU box with the repository snapshot; nothing is JIT-compiled at import time.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+CSRC = Path(__file__).resolve().parent / "csrc"
+LIB = CSRC / "libaether_hip.so"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
+
+
+def _sources():
+    return sorted(CSRC.glob("*.hip"))
+
+
+def _stale() -> bool:
+    if not LIB.exists():
+        return True
+    t = LIB.stat().st_mtime
+    deps = list(_sources()) + list(CSRC.glob("*.hpp")) + [CSRC.parent.parent / "include" / "aether_hip.h"]
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def _compile(src: Path, obj: Path):
+    cmd = [HIPCC, *FLAGS, "-c", str(src), "-o", str(obj)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stdout}\n{r.stderr}")
+
+
+def build_native(force: bool = False, verbose: bool = False) -> Path:
+    """Compile every .hip translation unit for gfx950 and link libaether_hip.so. Returns its path."""
+    if not force and not _stale():
+        return LIB
+    objdir = CSRC / "build"
+    objdir.mkdir(exist_ok=True)
+    srcs = _sources()
+    objs = [objdir / (s.stem + ".o") for s in srcs]
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        list(ex.map(lambda so: _compile(*so), zip(srcs, objs)))
+    cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, objs), "-o", str(LIB)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"built {LIB} from {len(srcs)} sources", file=sys.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    build_native(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,333 @@
+// HBM-bound kernels of the DiT forward (everything that is not a GEMM or attention):
+//   LayerNorm(+affine)+AdaLN modulation, the small fp32 GEMVs of the timestep / AdaLN path,
+//   sinusoidal timestep features, patchify / un-patchify, q/k LayerNorm + 3-D RoPE + head-major re-layout
+//   and the V transpose that feeds the attention kernel.
+// All of them stream 16 bytes per lane (bf16 x 8), keep fp32 statistics, and round to bf16 once.
+// Reference call site for all of them: the transformer call at
+// aether/pipelines/aetherv1_pipeline_cogvideox.py:865-875 (diffusers CogVideoXTransformer3DModel.forward).
+#include "common.hpp"
+#include "../../include/aether_hip.h"
+
+namespace aether {
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm + modulate: one wavefront per row, the row (<= 4096 elements) lives in registers.
+// ------------------------------------------------------------------------------------------------
+struct LnArgs {
+    const bf16_t* x; int ldx; bf16_t* y; int ldy; int rows, D; float eps;
+    const float* w; const float* b;
+    const float* shift_vid; const float* scale_vid; const float* shift_txt; const float* scale_txt;
+    int mod_bstride, rows_per_batch, n_text;
+};
+
+template <int NCH>  // D = NCH * 512
+__global__ __launch_bounds__(256) void layernorm_modulate_kernel(LnArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const bf16_t* xr = p.x + (size_t)row * p.ldx;
+    float v[NCH][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const u16x8 raw = *(const u16x8*)(xr + c * 512 + lane * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[c][e] = bf16_bits_to_f32(raw[e]); sum += v[c][e]; }
+    }
+    const float mean = wave_sum(sum) / (float)p.D;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; sq += d * d; }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)p.D + p.eps);
+
+    const float* shift = nullptr; const float* scale = nullptr;
+    if (p.shift_vid != nullptr) {
+        const int bidx = row / p.rows_per_batch;
+        const int t = row - bidx * p.rows_per_batch;
+        const bool txt = t < p.n_text;
+        shift = (txt ? p.shift_txt : p.shift_vid) + (size_t)bidx * p.mod_bstride;
+        scale = (txt ? p.scale_txt : p.scale_vid) + (size_t)bidx * p.mod_bstride;
+    }
+    bf16_t* yr = p.y + (size_t)row * p.ldy;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int d0 = c * 512 + lane * 8;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[c][e] - mean) * rstd;
+        if (p.w != nullptr) {
+            const f32x4 w0 = *(const f32x4*)(p.w + d0), w1 = *(const f32x4*)(p.w + d0 + 4);
+            const f32x4 b0 = *(const f32x4*)(p.b + d0), b1 = *(const f32x4*)(p.b + d0 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[e] = o[e] * w0[e] + b0[e]; o[e + 4] = o[e + 4] * w1[e] + b1[e]; }
+        }
+        if (shift != nullptr) {
+            const f32x4 s0 = *(const f32x4*)(scale + d0), s1 = *(const f32x4*)(scale + d0 + 4);
+            const f32x4 h0 = *(const f32x4*)(shift + d0), h1 = *(const f32x4*)(shift + d0 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = o[e] * (1.0f + s0[e]) + h0[e];
+                o[e + 4] = o[e + 4] * (1.0f + s1[e]) + h1[e];
+            }
+        }
+        uint4 out = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]),
+                               pack_bf16x2(o[6], o[7]));
+        *(uint4*)(yr + d0) = out;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[b,n] = act_out(bias[n] + sum_k act_in(x[b,k]) W[n,k]) — one wavefront per output feature n.
+// ------------------------------------------------------------------------------------------------
+template <int B>
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict__ x, int K, const bf16_t* __restrict__ W,
+                                                        const float* __restrict__ bias, float* __restrict__ out, int N,
+                                                        int act_in, int act_out) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const bf16_t* wr = W + (size_t)n * K;
+    float acc[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) acc[b] = 0.f;
+    for (int k0 = lane * 8; k0 < K; k0 += 512) {
+        const u16x8 raw = *(const u16x8*)(wr + k0);
+        float wv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wv[e] = bf16_bits_to_f32(raw[e]);
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            const f32x4 x0 = *(const f32x4*)(x + (size_t)b * K + k0), x1 = *(const f32x4*)(x + (size_t)b * K + k0 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a0 = x0[e], a1 = x1[e];
+                if (act_in == 1) { a0 = silu(a0); a1 = silu(a1); }
+                acc[b] += a0 * wv[e] + a1 * wv[e + 4];
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        float r = wave_sum(acc[b]);
+        if (lane == 0) {
+            if (bias != nullptr) r += bias[n];
+            if (act_out == 1) r = silu(r);
+            out[(size_t)b * N + n] = r;
+        }
+    }
+}
+
+__global__ void timestep_sinusoid_kernel(const float* __restrict__ t, int B, int dim, float* __restrict__ out) {
+    const int half = dim >> 1;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * half) return;
+    const int b = idx / half, i = idx - b * half;
+    const float freq = expf(-9.210340371976184f * (float)i / (float)half);  // ln(10000)
+    const float arg = t[b] * freq;
+    out[(size_t)b * dim + i] = cosf(arg);          // flip_sin_to_cos=True: [cos | sin]
+    out[(size_t)b * dim + half + i] = sinf(arg);
+}
+
+// ------------------------------------------------------------------------------------------------
+// patchify: x[B,F,C,H,W] -> A[(b,f,ph,pw), (c,dy,dx)]      (p = 2: each thread makes 4 consecutive columns)
+// ------------------------------------------------------------------------------------------------
+__global__ void patchify_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ A, int BF, int C,
+                                int H, int W, int p) {
+    const int PH = H / p, PW = W / p, pp = p * p;
+    const size_t total = (size_t)BF * PH * PW * C;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = idx % C;
+        size_t r = idx / C;
+        const int pw = r % PW; r /= PW;
+        const int ph = r % PH; r /= PH;
+        const size_t bf = r;
+        const unsigned short* src = x + ((bf * C + c) * H + (size_t)ph * p) * W + (size_t)pw * p;
+        unsigned short* dst = A + (((bf * PH + ph) * PW + pw) * C + c) * pp;
+        for (int dy = 0; dy < p; ++dy)
+            for (int dx = 0; dx < p; ++dx) dst[dy * p + dx] = src[(size_t)dy * W + dx];
+    }
+}
+
+// un-patchify: Y[(b,f,ph,pw), (dy,dx,c)] -> out[B,F,Cout,H,W]
+// (diffusers: output.reshape(B,F,H/p,W/p,-1,p,p).permute(0,1,4,2,5,3,6): proj_out column = c*p*p + dy*p + dx)
+__global__ void unpatchify_kernel(const unsigned short* __restrict__ Y, int ldy, unsigned short* __restrict__ out, int BF,
+                                  int Cout, int H, int W, int p) {
+    const int PH = H / p, PW = W / p;
+    const size_t total = (size_t)BF * Cout * H * W;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int w = idx % W;
+        size_t r = idx / W;
+        const int h = r % H; r /= H;
+        const int c = r % Cout; r /= Cout;
+        const size_t bf = r;
+        const int ph = h / p, dy = h - ph * p, pw = w / p, dx = w - pw * p;
+        out[idx] = Y[((bf * PH + ph) * PW + pw) * (size_t)ldy + (size_t)c * p * p + dy * p + dx];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// q/k LayerNorm(64) + RoPE + scale -> head-major Qh/Kh.  One block per token row; 8 lanes per (part, head).
+// ------------------------------------------------------------------------------------------------
+struct QkArgs {
+    const bf16_t* qkv; int S, H, n_text;
+    const float* qn_w; const float* qn_b; const float* kn_w; const float* kn_b; float eps;
+    const float* cos_t; const float* sin_t; float q_scale;
+    bf16_t* Qh; bf16_t* Kh;
+};
+
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(QkArgs p) {
+    const int row = blockIdx.x;              // b*S + s
+    const int b = row / p.S, s = row - b * p.S;
+    const int HD = p.H * 64;
+    const bf16_t* src = p.qkv + (size_t)row * 3 * HD;
+    const int items = 2 * p.H * 8;
+    const int vtok = s - p.n_text;
+    for (int it = threadIdx.x; it < items; it += 256) {
+        const int part = it / (p.H * 8);
+        const int rem = it - part * p.H * 8;
+        const int h = rem >> 3, sub = rem & 7;
+        const u16x8 raw = *(const u16x8*)(src + part * HD + h * 64 + sub * 8);
+        float v[8];
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[e] = bf16_bits_to_f32(raw[e]); sum += v[e]; }
+        sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64);
+        const float mean = sum * (1.0f / 64.0f);
+        float sq = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; sq += d * d; }
+        sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
+        const float rstd = rsqrtf(sq * (1.0f / 64.0f) + p.eps);
+        const float* nw = (part == 0 ? p.qn_w : p.kn_w) + sub * 8;
+        const float* nb = (part == 0 ? p.qn_b : p.kn_b) + sub * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean) * rstd * nw[e] + nb[e];
+        if (vtok >= 0) {
+            const float* cs = p.cos_t + (size_t)vtok * 64 + sub * 8;
+            const float* sn = p.sin_t + (size_t)vtok * 64 + sub * 8;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const float x0 = v[e], x1 = v[e + 1];
+                v[e] = x0 * cs[e] - x1 * sn[e];
+                v[e + 1] = x1 * cs[e + 1] + x0 * sn[e + 1];
+            }
+        }
+        const float sc = (part == 0) ? p.q_scale : 1.0f;
+        uint4 out = make_uint4(pack_bf16x2(v[0] * sc, v[1] * sc), pack_bf16x2(v[2] * sc, v[3] * sc),
+                               pack_bf16x2(v[4] * sc, v[5] * sc), pack_bf16x2(v[6] * sc, v[7] * sc));
+        bf16_t* dst = (part == 0 ? p.Qh : p.Kh) + (((size_t)b * p.H + h) * p.S + s) * 64 + sub * 8;
+        *(uint4*)dst = out;
+    }
+}
+
+// V[b,s,h,:] (inside qkv) -> Vt[b,h,d,s]; 64x64 tile through LDS; pad columns (s >= S) written as zero.
+__global__ __launch_bounds__(256) void v_transpose_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ Vt,
+                                                          int S, int H, int Spad) {
+    __shared__ unsigned short tile[64][66];
+    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+    const int s0 = blockIdx.x * 64;
+    const int HD = H * 64;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int piece = tid + i * 256;  // 512 pieces of 16 B: s_local = piece/8, chunk = piece%8
+        const int sl = piece >> 3, ch = piece & 7;
+        u16x8 raw = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (s0 + sl < S) raw = *(const u16x8*)(qkv + ((size_t)b * S + s0 + sl) * 3 * HD + 2 * HD + h * 64 + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tile[ch * 8 + e][sl] = raw[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int piece = tid + i * 256;  // d = piece/8, s chunk = piece%8
+        const int d = piece >> 3, ch = piece & 7;
+        u16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = tile[d][ch * 8 + e];
+        *(u16x8*)(Vt + ((size_t)bh * 64 + d) * Spad + s0 + ch * 8) = o;
+    }
+}
+
+}  // namespace aether
+
+using namespace aether;
+
+#define AE_STREAM ((hipStream_t)stream)
+
+extern "C" int aether_layernorm_modulate(const void* x, int ldx, void* y, int ldy, int rows, int D, float eps, const float* w,
+                                         const float* b, const float* shift_vid, const float* scale_vid,
+                                         const float* shift_txt, const float* scale_txt, int mod_bstride,
+                                         int rows_per_batch, int n_text, void* stream) {
+    if (!x || !y || rows <= 0) return aether_set_error(AETHER_ERR_ARG, "layernorm: bad arguments");
+    if (D % 512 != 0 || D > 4096 || D <= 0) return aether_set_error(AETHER_ERR_SHAPE, "layernorm: D must be a multiple of 512, <= 4096");
+    if ((ldx % 8) || (ldy % 8)) return aether_set_error(AETHER_ERR_ALIGN, "layernorm: leading dimensions must be multiples of 8");
+    if ((w == nullptr) != (b == nullptr)) return aether_set_error(AETHER_ERR_ARG, "layernorm: w and b must be given together");
+    const int nmod = (shift_vid != nullptr) + (scale_vid != nullptr) + (shift_txt != nullptr) + (scale_txt != nullptr);
+    if (nmod != 0 && nmod != 4) return aether_set_error(AETHER_ERR_ARG, "layernorm: give all four modulation vectors or none");
+    LnArgs p{(const bf16_t*)x, ldx, (bf16_t*)y, ldy, rows, D, eps, w, b, shift_vid, scale_vid, shift_txt, scale_txt,
+             mod_bstride, rows_per_batch > 0 ? rows_per_batch : rows, n_text};
+    dim3 grid((rows + 3) / 4), block(256);
+    switch (D / 512) {
+#define LN_CASE(n) case n: hipLaunchKernelGGL((layernorm_modulate_kernel<n>), grid, block, 0, AE_STREAM, p); break;
+        LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8)
+#undef LN_CASE
+    }
+    return aether_check_launch("layernorm_modulate");
+}
+
+extern "C" int aether_gemv_rows(const float* x, int B, int K, const void* W, const float* bias, float* out, int N, int act_in,
+                                int act_out, void* stream) {
+    if (!x || !W || !out) return aether_set_error(AETHER_ERR_ARG, "gemv: null pointer");
+    if (B < 1 || B > 8) return aether_set_error(AETHER_ERR_SHAPE, "gemv: 1 <= B <= 8");
+    if (K % 8 != 0 || K <= 0 || N <= 0) return aether_set_error(AETHER_ERR_SHAPE, "gemv: K must be a positive multiple of 8");
+    dim3 grid((N + 3) / 4), block(256);
+    const bf16_t* Wp = (const bf16_t*)W;
+    switch (B) {
+#define GV_CASE(n) case n: hipLaunchKernelGGL((gemv_rows_kernel<n>), grid, block, 0, AE_STREAM, x, K, Wp, bias, out, N, act_in, act_out); break;
+        GV_CASE(1) GV_CASE(2) GV_CASE(3) GV_CASE(4) GV_CASE(5) GV_CASE(6) GV_CASE(7) GV_CASE(8)
+#undef GV_CASE
+    }
+    return aether_check_launch("gemv_rows");
+}
+
+extern "C" int aether_timestep_sinusoid(const float* t_dev, int B, int dim, float* out, void* stream) {
+    if (!t_dev || !out || B <= 0 || dim <= 0 || (dim & 1)) return aether_set_error(AETHER_ERR_ARG, "timestep_sinusoid: bad arguments");
+    const int total = B * (dim / 2);
+    hipLaunchKernelGGL(timestep_sinusoid_kernel, dim3((total + 255) / 256), dim3(256), 0, AE_STREAM, t_dev, B, dim, out);
+    return aether_check_launch("timestep_sinusoid");
+}
+
+extern "C" int aether_patchify(const void* x, void* A, int B, int F, int C, int H, int W, int p, void* stream) {
+    if (!x || !A || p <= 0 || H % p || W % p) return aether_set_error(AETHER_ERR_SHAPE, "patchify: H, W must be multiples of p");
+    const size_t total = (size_t)B * F * (H / p) * (W / p) * C;
+    const int blocks = (int)min((size_t)8192, (total + 255) / 256);
+    hipLaunchKernelGGL(patchify_kernel, dim3(blocks), dim3(256), 0, AE_STREAM, (const unsigned short*)x, (unsigned short*)A, B * F, C, H, W, p);
+    return aether_check_launch("patchify");
+}
+
+extern "C" int aether_unpatchify(const void* Y, int ldy, void* out, int B, int F, int Cout, int H, int W, int p, void* stream) {
+    if (!Y || !out || p <= 0 || H % p || W % p || ldy < Cout * p * p) return aether_set_error(AETHER_ERR_SHAPE, "unpatchify: bad shape");
+    const size_t total = (size_t)B * F * Cout * H * W;
+    const int blocks = (int)min((size_t)8192, (total + 255) / 256);
+    hipLaunchKernelGGL(unpatchify_kernel, dim3(blocks), dim3(256), 0, AE_STREAM, (const unsigned short*)Y, ldy, (unsigned short*)out, B * F, Cout, H, W, p);
+    return aether_check_launch("unpatchify");
+}
+
+extern "C" int aether_qk_norm_rope(const void* qkv, int B, int S, int H, int n_text, const float* qn_w, const float* qn_b,
+                                   const float* kn_w, const float* kn_b, float eps, const float* cos_t, const float* sin_t,
+                                   float q_scale, void* Qh, void* Kh, void* Vt, int Spad, void* stream) {
+    if (!qkv || !Qh || !Kh || !Vt || !qn_w || !qn_b || !kn_w || !kn_b) return aether_set_error(AETHER_ERR_ARG, "qk_norm_rope: null pointer");
+    if (B <= 0 || S <= 0 || H <= 0 || n_text < 0 || n_text > S) return aether_set_error(AETHER_ERR_SHAPE, "qk_norm_rope: bad shape");
+    if (n_text < S && (!cos_t || !sin_t)) return aether_set_error(AETHER_ERR_ARG, "qk_norm_rope: rope tables required");
+    if (Spad % 64 != 0 || Spad < S) return aether_set_error(AETHER_ERR_SHAPE, "qk_norm_rope: Spad must be roundup(S,64)");
+    QkArgs p{(const bf16_t*)qkv, S, H, n_text, qn_w, qn_b, kn_w, kn_b, eps, cos_t, sin_t, q_scale, (bf16_t*)Qh, (bf16_t*)Kh};
+    hipLaunchKernelGGL(qk_norm_rope_kernel, dim3(B * S), dim3(256), 0, AE_STREAM, p);
+    int rc = aether_check_launch("qk_norm_rope");
+    if (rc) return rc;
+    hipLaunchKernelGGL(v_transpose_kernel, dim3(Spad / 64, B * H), dim3(256), 0, AE_STREAM, (const unsigned short*)qkv,
+                       (unsigned short*)Vt, S, H, Spad);
+    return aether_check_launch("v_transpose");
+}

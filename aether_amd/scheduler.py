@@ -1,0 +1,143 @@
+"""Host-side stand-in for diffusers' `CogVideoXDPMScheduler` as the reference drives it
+(/root/reference/scripts/demo.py:220-222 builds it; /root/reference/aether/pipelines/aetherv1_pipeline_cogvideox.py
+uses `set_timesteps` via P:227, `scale_model_input` P:835, `step` P:907-915, `init_noise_sigma` P:686, `order` P:821).
+
+The schedule is a few hundred float64 scalars and the update is element-wise over 3.3 M latent values per step, so
+it stays host-driven PyTorch — what matters for parity is that the random draws (count, order,
+shape, dtype, device of every `randn`) and the dtype of every intermediate are those of the reference: scalars are
+0-dim float64 CPU tensors exactly like diffusers' `alphas_cumprod[t]`, so PyTorch's type promotion rounds the same
+products to bf16 / fp32 as it does there.  Algorithm restated from diffusers 0.32 schedulers/scheduling_dpm_cogvideox.py
+(SDE DPM-Solver++(2M), v-prediction, zero-terminal-SNR + SNR-shifted scaled-linear betas) — UPSTREAM-UNVERIFIED.
+"""
+from __future__ import annotations
+
+import json
+import os
+from types import SimpleNamespace
+from typing import Optional
+
+import numpy as np
+import torch
+
+
+def randn_tensor(shape, generator=None, device=None, dtype=None):
+    """diffusers.utils.torch_utils.randn_tensor: draw on the generator's device, then move (P:683)."""
+    device = torch.device(device) if device is not None else torch.device("cpu")
+    if isinstance(generator, list):
+        shape = (1,) + tuple(shape[1:])
+        return torch.cat([randn_tensor(shape, g, device, dtype) for g in generator], dim=0)
+    rand_device = device
+    if generator is not None:
+        gen_type = generator.device.type
+        if gen_type != device.type and gen_type == "cpu":
+            rand_device = torch.device("cpu")
+        elif gen_type != device.type and gen_type == "cuda":
+            raise ValueError(f"Cannot generate a {device} tensor from a generator of type {gen_type}.")
+    return torch.randn(tuple(shape), generator=generator, device=rand_device, dtype=dtype).to(device)
+
+
+def _rescale_zero_terminal_snr(alphas_cumprod: torch.Tensor) -> torch.Tensor:
+    a = alphas_cumprod.sqrt()
+    a0, aT = a[0].clone(), a[-1].clone()
+    a = (a - aT) * (a0 / (a0 - aT))
+    return a ** 2
+
+
+class CogVideoXDPMScheduler:
+    order = 1
+    _defaults = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                     clip_sample=False, set_alpha_to_one=True, steps_offset=0, prediction_type="v_prediction",
+                     timestep_spacing="trailing", rescale_betas_zero_snr=True, snr_shift_scale=1.0)
+
+    def __init__(self, **config):
+        cfg = dict(self._defaults)
+        cfg.update({k: v for k, v in config.items() if k in cfg})
+        self.config = SimpleNamespace(**cfg)
+        c = self.config
+        if c.beta_schedule == "scaled_linear":
+            betas = torch.linspace(c.beta_start ** 0.5, c.beta_end ** 0.5, c.num_train_timesteps, dtype=torch.float64) ** 2
+        elif c.beta_schedule == "linear":
+            betas = torch.linspace(c.beta_start, c.beta_end, c.num_train_timesteps, dtype=torch.float32)
+        else:
+            raise NotImplementedError(f"{c.beta_schedule} is not implemented for {self.__class__}")
+        self.betas = betas
+        self.alphas = 1.0 - betas
+        ac = torch.cumprod(self.alphas, dim=0)
+        ac = ac / (c.snr_shift_scale + (1 - c.snr_shift_scale) * ac)
+        if c.rescale_betas_zero_snr:
+            ac = _rescale_zero_terminal_snr(ac)
+        self.alphas_cumprod = ac
+        self.final_alpha_cumprod = torch.tensor(1.0) if c.set_alpha_to_one else ac[0]
+        self.init_noise_sigma = 1.0
+        self.num_inference_steps = None
+        self.timesteps = torch.from_numpy(np.arange(0, c.num_train_timesteps)[::-1].copy().astype(np.int64))
+
+    @classmethod
+    def from_pretrained(cls, path, subfolder: Optional[str] = "scheduler", **_):
+        root = os.path.join(path, subfolder) if subfolder else path
+        with open(os.path.join(root, "scheduler_config.json")) as f:
+            return cls(**{k: v for k, v in json.load(f).items() if not k.startswith("_")})
+
+    @classmethod
+    def from_config(cls, config, **kw):
+        return cls(**(dict(config) if isinstance(config, dict) else vars(config)), **kw)
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        c = self.config
+        if num_inference_steps > c.num_train_timesteps:
+            raise ValueError(f"`num_inference_steps`: {num_inference_steps} cannot be larger than `self.config.train_timesteps`:"
+                             f" {c.num_train_timesteps}")
+        self.num_inference_steps = num_inference_steps
+        if c.timestep_spacing == "linspace":
+            ts = np.linspace(0, c.num_train_timesteps - 1, num_inference_steps).round()[::-1].copy().astype(np.int64)
+        elif c.timestep_spacing == "leading":
+            ratio = c.num_train_timesteps // num_inference_steps
+            ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64) + c.steps_offset
+        elif c.timestep_spacing == "trailing":
+            ratio = c.num_train_timesteps / num_inference_steps
+            ts = np.round(np.arange(c.num_train_timesteps, 0, -ratio)).astype(np.int64) - 1
+        else:
+            raise ValueError(f"{c.timestep_spacing} is not supported.")
+        self.timesteps = torch.from_numpy(ts).to(device)
+
+    @staticmethod
+    def _lambda(a):
+        return ((a / (1 - a)) ** 0.5).log()
+
+    def step(self, model_output, old_pred_original_sample, timestep, timestep_back, sample, eta: float = 0.0,
+             use_clipped_model_output: bool = False, generator=None, variance_noise=None, return_dict: bool = False):
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
+        c = self.config
+        t = int(timestep)
+        prev_t = t - c.num_train_timesteps // self.num_inference_steps
+        a_t = self.alphas_cumprod[t]
+        a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
+        a_back = self.alphas_cumprod[int(timestep_back)] if timestep_back is not None else None
+        beta_t = 1 - a_t
+        if c.prediction_type == "epsilon":
+            x0 = (sample - beta_t ** 0.5 * model_output) / a_t ** 0.5
+        elif c.prediction_type == "sample":
+            x0 = model_output
+        elif c.prediction_type == "v_prediction":
+            x0 = (a_t ** 0.5) * sample - (beta_t ** 0.5) * model_output
+        else:
+            raise ValueError(f"prediction_type given as {c.prediction_type} must be one of `epsilon`, `sample`, or `v_prediction`")
+        lamb, lamb_next = self._lambda(a_t), self._lambda(a_prev)
+        h = lamb_next - lamb
+        m1 = ((1 - a_prev) / (1 - a_t)) ** 0.5 * (-h).exp()
+        m2 = (-2 * h).expm1() * a_prev ** 0.5
+        m_noise = (1 - a_prev) ** 0.5 * (1 - (-2 * h).exp()) ** 0.5
+        noise = randn_tensor(sample.shape, generator=generator, device=sample.device, dtype=sample.dtype)
+        prev_sample = m1 * sample - m2 * x0 + m_noise * noise
+        if old_pred_original_sample is None or prev_t < 0:
+            return (prev_sample, x0)
+        r = (lamb - self._lambda(a_back)) / h
+        m3, m4 = 1 + 1 / (2 * r), 1 / (2 * r)
+        d = m3 * x0 - m4 * old_pred_original_sample
+        noise = randn_tensor(sample.shape, generator=generator, device=sample.device, dtype=sample.dtype)
+        prev_sample = m1 * sample - m2 * d + m_noise * noise
+        return (prev_sample, x0)

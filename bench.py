@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""Headline benchmark: denoise-steps/s of the AetherV1 sampling loop on a 41-frame 480x720 clip
+(latent 11x60x90 -> 226 + 14 850 tokens, 42-layer / 3072-wide DiT, bf16), BASELINE.json configs[1]:
+"4D reconstruction, 41x480x720, 50 steps, bf16, 1xMI355X" (B = 1 through the transformer, no CFG).
+
+One "step" = exactly what the reference's loop body does per iteration (P:827-916): concat noisy latents with the
+condition latents, one transformer forward, fp32 cast, one CogVideoXDPMScheduler.step (two generator draws), cast
+back to bf16.  Inputs (synthetic, seeded) and the random-init weights are resident in HBM before the timed region.
+N > 1: one process per GPU, each rank denoises its own independent window (the reference's sliding windows are
+independent pipeline calls, scripts/demo.py:613-631) -> weak scaling, no data-path collective.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel class
+(HIP-event timing recorded on the launch stream inside aether_dit_forward during the timed steps) and `cpu_baseline`
+(the fp32 oracle timed on this host's cores on a bounded sample, rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0   # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md:42
+HBM_PEAK_GBPS = 8000.0      # spec, MI355X_MICROARCH.md:35
+
+
+def flops_per_launch(cls: str, B: int, S: int, D: int, FF: int) -> float:
+    """ALGORITHMIC flops of one launch of a kernel class (multiply-add = 2)."""
+    M = B * S
+    return {
+        "attention": 4.0 * B * S * S * D,          # QK^T + PV over all heads: 4*S^2*64*H
+        "gemm_qkv": 2.0 * M * 3 * D * D,
+        "gemm_out": 2.0 * M * D * D,
+        "gemm_ff1": 2.0 * M * FF * D,
+        "gemm_ff2": 2.0 * M * D * FF,
+    }.get(cls, 0.0)
+
+
+def cpu_baseline(cfg_overrides, S_video_shape, seconds_budget=30.0):
+    """fp32 oracle (oracle/dit.py) on the host cores: ONE transformer block at the full token count, extrapolated to
+    the 42-block forward (blocks are identical; embeddings/final layers are <0.1 % of the flops)."""
+    from oracle.dit import Block, DitConfig
+
+    cfg = DitConfig(**cfg_overrides)
+    torch.manual_seed(0)
+    blk = Block(cfg).float().eval()
+    F_, H_, W_ = S_video_shape
+    n_vid = F_ * (H_ // 2) * (W_ // 2)
+    h = torch.randn(1, n_vid, cfg.inner_dim)
+    e = torch.randn(1, cfg.max_text_seq_length, cfg.inner_dim)
+    temb = torch.randn(1, cfg.time_embed_dim)
+    ang = torch.rand(n_vid, 32)
+    rope = (ang.cos().repeat_interleave(2, 1), ang.sin().repeat_interleave(2, 1))
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        blk(h, e, temb, rope)
+        dt = time.perf_counter() - t0
+    steps_per_s = 1.0 / (dt * cfg.num_layers)
+    return {"value": steps_per_s, "unit": "denoise-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 of {cfg.num_layers} DiT blocks at full size (B=1, S={n_vid + cfg.max_text_seq_length}, fp32 torch-CPU "
+                      f"oracle, {dt:.1f} s), extrapolated x{cfg.num_layers}; host has {os.cpu_count()} logical cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--layers", type=int, default=42, help="debug only; anything but 42 marks the line invalid")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cfg", action="store_true", help="B=2 (prediction/planning CFG) instead of reconstruction B=1")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    from aether_amd.rope import resize_crop_region_for_grid, rotary_tables_3d
+    from aether_amd.scheduler import CogVideoXDPMScheduler, randn_tensor
+    from aether_amd.transformer import AetherTransformer3D
+
+    B = 2 if args.cfg else 1
+    F_, H_, W_ = 11, 60, 90
+    model = AetherTransformer3D({"num_layers": args.layers}, device=dev).init_random_weights(seed=0)
+    c = model.config
+    D, FF = model.inner_dim, 4 * model.inner_dim
+    S = c.max_text_seq_length + F_ * (H_ // 2) * (W_ // 2)
+
+    gen = torch.Generator(device=dev).manual_seed(42 + rank)          # scripts/demo.py:93-97 seed, one window per rank
+    prompt = (torch.randn(1, c.max_text_seq_length, c.text_embed_dim, generator=gen, device=dev) * 0.1).to(torch.bfloat16)
+    cond = torch.randn(1, F_, 40, H_, W_, generator=gen, device=dev).to(torch.bfloat16)     # 16 latent + 24 raymap ch (P:682)
+    latents = randn_tensor((1, F_, 56, H_, W_), generator=gen, device=dev, dtype=torch.bfloat16)
+    crop = resize_crop_region_for_grid((H_ // 2, W_ // 2), c.sample_width // 2, c.sample_height // 2)
+    rope = rotary_tables_3d(64, crop, (H_ // 2, W_ // 2), F_, 1.0, device=dev)
+    sched = CogVideoXDPMScheduler()
+    sched.set_timesteps(50, device=dev)
+    timesteps = sched.timesteps
+    ts_host = timesteps.tolist()
+
+    state = {"latents": latents, "old_x0": None, "i": 0}
+
+    def step():
+        i = state["i"] % len(ts_host)
+        if i == 0:
+            state["old_x0"] = None
+        t = timesteps[i]
+        lat = state["latents"]
+        model_in = torch.cat([lat] * 2) if B == 2 else lat
+        cnd = torch.cat([cond] * 2) if B == 2 else cond
+        model_in = torch.cat([model_in, cnd], dim=2)                                          # P:857-859
+        noise_pred = model(hidden_states=model_in, encoder_hidden_states=prompt.repeat(B, 1, 1), timestep=t.expand(B),
+                           ofs=None, image_rotary_emb=rope, attention_kwargs=None, return_dict=False)[0].float()
+        if B == 2:
+            u, tx = noise_pred.chunk(2)
+            noise_pred = u + 3.0 * (tx - u)
+        lat, state["old_x0"] = sched.step(noise_pred, state["old_x0"], ts_host[i], ts_host[i - 1] if i > 0 else None, lat,
+                                          generator=gen, return_dict=False)
+        state["latents"] = lat.to(torch.bfloat16)
+        state["i"] += 1
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    model.set_profile(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = model.get_profile()
+    model.set_profile(False)
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    assert torch.isfinite(state["latents"].float()).all(), "non-finite latents"
+
+    if rank == 0:
+        steps_per_s = world * args.steps / elapsed
+        total_ms = sum(ms for ms, _ in prof.values())
+        dom = max((k for k in prof if flops_per_launch(k, B, S, D, FF) > 0), key=lambda k: prof[k][0])
+        dom_ms, dom_n = prof[dom]
+        fl = flops_per_launch(dom, B, S, D, FF)
+        ach = fl / (dom_ms / dom_n * 1e-3) / 1e12
+        line = {
+            "metric": "denoise-steps/s (41f 480x720 clip, 11x60x90 latent, B=%d through the DiT)" % B,
+            "value": steps_per_s, "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic (seeded latents/conditions/prompt embeds; random-init weights, 5.57 B params)",
+            "config": {"workload": ("configs[2]-style CFG step" if B == 2 else "configs[1]: 4D reconstruction 41x480x720, bf16, 1 window per GPU"),
+                       "tokens": S, "layers": c.num_layers, "width": D, "heads": c.num_attention_heads, "batch_through_dit": B,
+                       "scheduler": "CogVideoXDPMScheduler(50 steps)", "valid": args.layers == 42},
+            "mfma_frac_whole_step": steps_per_s / world * B * 260.8e12 / (MFMA_PEAK_TFLOPS * 1e12),
+            "roofline": {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": dom_ms / dom_n, "launches": dom_n,
+                         "algorithmic_flops_per_launch": fl},
+            "kernel_ms_per_step": {k: round(ms / args.steps, 3) for k, (ms, _) in prof.items()},
+            "kernel_tflops": {k: round(flops_per_launch(k, B, S, D, FF) * n / (ms * 1e-3) / 1e12, 1) for k, (ms, n) in prof.items()
+                              if flops_per_launch(k, B, S, D, FF) > 0 and ms > 0},
+            "gpu_kernel_ms_per_step_total": total_ms / args.steps,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            del model
+            torch.cuda.empty_cache()
+            line["cpu_baseline"] = cpu_baseline({"num_layers": args.layers}, (F_, H_, W_))
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

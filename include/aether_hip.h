@@ -1,0 +1,165 @@
+/*
+ * aether_hip.h — C ABI of libaether_hip.so, the MI355X (gfx950) implementation of the AetherV1
+ * latent-video denoising hot path.
+ *
+ * The reference (InternRobotics/Aether) has no native interface: its hot path is Python that calls three
+ * diffusers objects at a handful of call sites.  Each entry point below states the reference call site
+ * (file:line in /root/reference) whose arithmetic it replaces.  P: = aether/pipelines/aetherv1_pipeline_cogvideox.py.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless marked host; the caller (PyTorch) owns every buffer;
+ *     the library never allocates or frees device memory and keeps no pointer past a call except the
+ *     weight table registered on an explicit handle (aether_dit_*, aether_vae_*).
+ *   - bf16 tensors are passed as void* (2 bytes / element, row-major, 16-byte aligned base + rows).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Kernels are only enqueued.
+ *   - return value: 0 = ok, negative = AETHER_ERR_*; text via aether_last_error() (thread local).
+ *   - no exception crosses this boundary.
+ */
+#ifndef AETHER_HIP_H
+#define AETHER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AETHER_OK 0
+#define AETHER_ERR_ARG (-1)    /* null / inconsistent argument                 */
+#define AETHER_ERR_SHAPE (-2)  /* unsupported shape (see the entry's contract) */
+#define AETHER_ERR_ALIGN (-3)  /* pointer or leading dimension not 16-B aligned */
+#define AETHER_ERR_ARCH (-4)   /* device is not gfx950                          */
+#define AETHER_ERR_LAUNCH (-5) /* HIP launch error                              */
+
+const char* aether_last_error(void);
+int aether_version(void);
+/* 0 if the current HIP device is a gfx950 part, AETHER_ERR_ARCH otherwise (host-side query). */
+int aether_check_device(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-kernel entry points (used by the native transformer / VAE and by the parity tests)
+ * ------------------------------------------------------------------------------------------------ */
+
+/* GEMM epilogues */
+#define AETHER_EPI_BIAS 0          /* C = A·Wᵀ + bias                                           */
+#define AETHER_EPI_BIAS_GELU 1     /* C = gelu_tanh(A·Wᵀ + bias)                                 */
+#define AETHER_EPI_BIAS_GATE_RES 2 /* C = R + gate[b(m),type(m),:] ⊙ (A·Wᵀ + bias)               */
+#define AETHER_GEMM_WIDE_STORE 1   /* flags bit: 16-byte stores through a half-wave exchange      */
+
+/* C[M,N] = epi(A[M,K] · W[N,K]ᵀ), bf16 in / bf16 out / fp32 accumulate on MFMA.
+ * Replaces nn.Linear in CogVideoXBlock / CogVideoXPatchEmbed / proj_out under P:865-875
+ * (to_q,to_k,to_v fused as one [3D,D] weight; to_out.0; ff.net.0.proj; ff.net.2; patch_embed.proj as a
+ * GEMM over 2x2 patches; text_proj; proj_out).  K % 64 == 0, N % 32 == 0, ld* % 8 == 0.
+ * bias fp32 [N] or NULL.  R (bf16 [M,N], ldr) and the gates apply to AETHER_EPI_BIAS_GATE_RES only:
+ * row m belongs to batch b = m / rows_per_batch and is a text row iff (m % rows_per_batch) < n_text;
+ * gate = (text ? gate_txt : gate_vid)[b*gate_bstride + n]; NULL gates mean 1.  R may alias C. */
+int aether_gemm_bf16(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
+                     const float* bias, int epilogue, const void* R, int ldr, const float* gate_vid,
+                     const float* gate_txt, int gate_bstride, int rows_per_batch, int n_text, int flags,
+                     void* stream);
+
+/* y = LayerNorm(x; eps)·w + b, then optionally y·(1+scale)+shift with per-batch, per-row-type
+ * modulation vectors (fp32).  Replaces CogVideoXLayerNormZero.norm + modulation, norm_final, and
+ * AdaLayerNorm (norm_out) of the transformer called at P:865-875.  x,y bf16 [rows, D]; D % 512 == 0,
+ * D <= 4096; w,b fp32 [D] or NULL; the shift_x / scale_x vectors are fp32, indexed [b*mod_bstride + d] or all NULL. */
+int aether_layernorm_modulate(const void* x, int ldx, void* y, int ldy, int rows, int D, float eps,
+                              const float* w, const float* b, const float* shift_vid, const float* scale_vid,
+                              const float* shift_txt, const float* scale_txt, int mod_bstride,
+                              int rows_per_batch, int n_text, void* stream);
+
+/* out[b,n] = act_out(bias[n] + sum_k act_in(x[b,k]) · W[n,k]);  x fp32 [B,K], W bf16 [N,K], out fp32.
+ * act codes: 0 none, 1 SiLU.  One wavefront per output feature; B <= 8; K % 8 == 0.
+ * Replaces TimestepEmbedding.linear_1/linear_2 and every CogVideoXLayerNormZero.linear /
+ * AdaLayerNorm.linear (all layers in ONE launch: their weights are concatenated along N). */
+int aether_gemv_rows(const float* x, int B, int K, const void* W, const float* bias, float* out, int N,
+                     int act_in, int act_out, void* stream);
+
+/* Sinusoidal timestep features, diffusers Timesteps(dim, flip_sin_to_cos=True, freq_shift=0):
+ * out[b, 0:dim/2] = cos(t·f), out[b, dim/2:] = sin(t·f), f_i = exp(-ln(1e4)·i/(dim/2)).  t_dev: fp32 [B] on device. */
+int aether_timestep_sinusoid(const float* t_dev, int B, int dim, float* out, void* stream);
+
+/* Patchify for CogVideoXPatchEmbed (patch_size_t = None): x bf16 [B,F,C,H,W] ->
+ * A bf16 [B*F*(H/p)*(W/p), C*p*p] with column order (c, dy, dx) = Conv2d weight.flatten(1) order. */
+int aether_patchify(const void* x, void* A, int B, int F, int C, int H, int W, int p, void* stream);
+
+/* Inverse of the un-patchify reshape at the end of CogVideoXTransformer3DModel.forward:
+ * Y bf16 [B*F*(H/p)*(W/p), ldy] (first p*p*Cout columns used, column order (c, dy, dx)) -> out bf16 [B,F,Cout,H,W]. */
+int aether_unpatchify(const void* Y, int ldy, void* out, int B, int F, int Cout, int H, int W, int p, void* stream);
+
+/* q/k LayerNorm(head_dim) + 3-D RoPE + head-major re-layout.  Replaces CogVideoXAttnProcessor2_0's
+ * norm_q/norm_k + apply_rotary_emb (adjacent-pair convention, fp32) under P:865-875.
+ * qkv bf16 [B,S,3*H*64] (q | k | v thirds) -> Qh,Kh bf16 [B,H,S,64] and Vt bf16 [B,H,64,Spad]
+ * (V transposed, Spad = roundup(S,64), pad columns zeroed).  Rows [0,n_text) of each batch are text rows
+ * (no RoPE); cos,sin fp32 [S-n_text, 64].  Q is additionally multiplied by q_scale (1/sqrt(64), exact in bf16). */
+int aether_qk_norm_rope(const void* qkv, int B, int S, int H, int n_text, const float* qn_w, const float* qn_b,
+                        const float* kn_w, const float* kn_b, float eps, const float* cos_t, const float* sin_t,
+                        float q_scale, void* Qh, void* Kh, void* Vt, int Spad, void* stream);
+
+/* Non-causal flash attention, head_dim 64: O[b,s,h*64+d] = softmax(Qh·Khᵀ)·V  (scale pre-folded into Qh).
+ * Replaces F.scaled_dot_product_attention in CogVideoXAttnProcessor2_0.  Qh,Kh [B,H,S,64], Vt [B,H,64,Spad],
+ * O bf16 [B,S,H*64].  flags: AETHER_GEMM_WIDE_STORE selects the 16-byte epilogue store. */
+int aether_flash_attn_fwd(const void* Qh, const void* Kh, const void* Vt, void* O, int B, int H, int S, int Spad,
+                          int flags, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole-transformer entry (one call = CogVideoXTransformer3DModel.forward as invoked at P:865-875)
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct AetherDitConfig {
+    int num_layers;         /* 42 */
+    int num_heads;          /* 48 */
+    int head_dim;           /* 64 (only 64 is implemented) */
+    int in_channels;        /* 96 */
+    int out_channels;       /* 56 */
+    int patch_size;         /* 2 */
+    int text_dim;           /* 4096 */
+    int time_embed_dim;     /* 512 */
+    int ff_mult;            /* 4 */
+    int max_text_len;       /* 226 */
+    float norm_eps;         /* 1e-5 */
+    float qk_norm_eps;      /* 1e-6 */
+    int use_pos_embedding;  /* add pos_embedding [text+video, D] after patch embed */
+    int flags;              /* AETHER_GEMM_* flags forwarded to the GEMMs */
+} AetherDitConfig;
+
+typedef struct AetherDit AetherDit; /* opaque host-side handle: weight table + launch plan */
+
+AetherDit* aether_dit_create(const AetherDitConfig* cfg);
+void aether_dit_destroy(AetherDit* h);
+/* Register a device weight by its diffusers state-dict-derived name (see aether_amd/transformer.py for the
+ * packing: fused qkv, concatenated AdaLN linears, fp32 biases/norm params).  Pointer must stay valid. */
+int aether_dit_set_weight(AetherDit* h, const char* name, const void* dev_ptr);
+/* Bytes of scratch the forward needs for batch B and a latent grid F x H x W (latent pixels). */
+size_t aether_dit_workspace_bytes(const AetherDit* h, int B, int F, int H, int W);
+/* hidden bf16 [B,F,in_channels,H,W]; text bf16 [B,max_text_len,text_dim]; timesteps fp32 [B] (device);
+ * rope cos/sin fp32 [F*(H/p)*(W/p), 64]; out bf16 [B,F,out_channels,H,W]; workspace >= workspace_bytes. */
+int aether_dit_forward(AetherDit* h, const void* hidden, const void* text, const float* timesteps,
+                       const float* rope_cos, const float* rope_sin, void* out, int B, int F, int H, int W,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* Optional per-kernel-class timing of aether_dit_forward: hipEvents are recorded on the launch stream around
+ * every enqueue while enabled (do not enable during hipGraph capture).  aether_dit_get_profile synchronises on
+ * the recorded events, ADDS UP milliseconds and launch counts per class since the last call, and resets. */
+#define AETHER_PROF_OTHER 0     /* embeddings, timestep/AdaLN GEMVs, final norms, proj_out, (un)patchify */
+#define AETHER_PROF_LN 1        /* LayerNorm + modulation                                                */
+#define AETHER_PROF_GEMM_QKV 2
+#define AETHER_PROF_QKROPE 3    /* q/k LayerNorm + RoPE + V transpose                                    */
+#define AETHER_PROF_ATTN 4      /* flash attention                                                       */
+#define AETHER_PROF_GEMM_O 5
+#define AETHER_PROF_GEMM_FF1 6
+#define AETHER_PROF_GEMM_FF2 7
+#define AETHER_PROF_NUM 8
+int aether_dit_set_profile(AetherDit* h, int enable);
+int aether_dit_get_profile(AetherDit* h, float* ms_per_class /*[AETHER_PROF_NUM]*/, int* launches_per_class);
+
+#ifdef __cplusplus
+}
+#endif
+
+/* internal helpers shared by the translation units of the library (not part of the ABI) */
+#ifdef __cplusplus
+extern "C" int aether_set_error(int code, const char* msg);
+extern "C" int aether_check_launch(const char* what);
+#endif
+
+#endif /* AETHER_HIP_H */

@@ -1,0 +1,234 @@
+"""Per-kernel parity: each HIP entry point of include/aether_hip.h against a plain fp32 PyTorch evaluation of the
+same operator on the same seeded bf16 inputs (the floating-point tolerance is written next to each check)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel_l2(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+
+
+def _bf16_close(got, ref_fp32, what, rel=6e-3, max_ulp_frac=2.0):
+    """bf16 output of an fp32-accumulated op: relative L2 within bf16 rounding noise (2^-9 ≈ 2e-3 rms bound
+    per element → 6e-3 leaves room for the reference's own reduction-order noise) and every element within
+    `max_ulp_frac` bf16 ulps of the fp32 value, relative to the tensor's scale."""
+    got32 = got.float().cpu()
+    ref = ref_fp32.float().cpu()
+    assert torch.isfinite(got32).all(), f"{what}: non-finite output"
+    r = _rel_l2(got32, ref)
+    assert r < rel, f"{what}: rel-L2 {r:.3e} >= {rel}"
+    scale = ref.abs().max().item()
+    linf = (got32 - ref).abs().max().item()
+    assert linf <= max_ulp_frac * 2 ** -8 * max(scale, 1e-6), f"{what}: Linf {linf:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 256), (300, 256, 128), (1000, 512, 3072), (226, 512, 4096), (37, 224, 512)])
+@pytest.mark.parametrize("flags", [0, 1])
+def test_gemm_bias(cuda, hip_lib, M, N, K, flags):
+    from aether_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = (torch.randn(M, K, generator=g)).to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g)
+    ref = A.float() @ W.float().t() + bias
+    out = ops.gemm_bf16(A.to(cuda), W.to(cuda), bias.to(cuda), ops.AETHER_EPI_BIAS, flags=flags)
+    torch.cuda.synchronize()
+    _bf16_close(out, ref, f"gemm {M}x{N}x{K}")
+
+
+def test_gemm_transpose_detecting(cuda, hip_lib):
+    """A = I-like, asymmetric W: catches a swapped row/column in the C write (guide rule 16)."""
+    from aether_amd import ops
+    M = N = K = 256
+    A = torch.eye(M, K).to(torch.bfloat16)
+    W = (torch.arange(N)[:, None] * 0.5 + torch.arange(K)[None, :] * 0.001953125).to(torch.bfloat16)  # W[n,k]
+    out = ops.gemm_bf16(A.to(cuda), W.to(cuda), None, ops.AETHER_EPI_BIAS)
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu().float(), W.float().t())
+
+
+@pytest.mark.parametrize("flags", [0, 1])
+def test_gemm_gelu(cuda, hip_lib, flags):
+    from aether_amd import ops
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 700, 1024, 512
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g) * 2 / math.sqrt(K)).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g)
+    ref = torch.nn.functional.gelu(A.float() @ W.float().t() + bias, approximate="tanh")
+    out = ops.gemm_bf16(A.to(cuda), W.to(cuda), bias.to(cuda), ops.AETHER_EPI_BIAS_GELU, flags=flags)
+    torch.cuda.synchronize()
+    _bf16_close(out, ref, "gemm+gelu")
+
+
+@pytest.mark.parametrize("flags", [0, 1])
+def test_gemm_gate_residual_inplace(cuda, hip_lib, flags):
+    from aether_amd import ops
+    g = torch.Generator().manual_seed(6)
+    B, S, n_text, N, K = 2, 333, 20, 512, 256
+    M = B * S
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g).to(torch.bfloat16)
+    mod = torch.randn(B, 4 * N, generator=g)          # gates live inside a wider modulation buffer
+    gate_vid, gate_txt = mod[:, N:2 * N], mod[:, 3 * N:]
+    y = A.float() @ W.float().t() + bias
+    rows = torch.arange(M)
+    b_idx, is_txt = rows // S, (rows % S) < n_text
+    gsel = torch.where(is_txt[:, None], gate_txt[b_idx], gate_vid[b_idx])
+    ref = R.float() + gsel * y
+    x = R.to(cuda).clone()
+    modc = mod.to(cuda)
+    ops.gemm_bf16(A.to(cuda), W.to(cuda), bias.to(cuda), ops.AETHER_EPI_BIAS_GATE_RES, R=x, gate_vid=modc[:, N:2 * N],
+                  gate_txt=modc[:, 3 * N:], rows_per_batch=S, n_text=n_text, out=x, flags=flags)
+    torch.cuda.synchronize()
+    _bf16_close(x, ref, "gemm+gate+res")
+
+
+def test_gemm_rejects_bad_shapes(cuda, hip_lib):
+    from aether_amd import ops
+    A = torch.zeros(64, 100, dtype=torch.bfloat16, device=cuda)
+    W = torch.zeros(64, 100, dtype=torch.bfloat16, device=cuda)
+    with pytest.raises(ValueError):
+        ops.gemm_bf16(A, W)
+
+
+@pytest.mark.parametrize("D", [512, 3072, 4096])
+def test_layernorm_modulate(cuda, hip_lib, D):
+    from aether_amd import ops
+    g = torch.Generator().manual_seed(D)
+    B, S, n_text = 2, 101, 9
+    x = (torch.randn(B * S, D, generator=g) * 3 + 0.5).to(torch.bfloat16)
+    w, b = 1 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    mod = torch.randn(B, 6 * D, generator=g) * 0.5
+    sh_v, sc_v, sh_t, sc_t = mod[:, :D], mod[:, D:2 * D], mod[:, 3 * D:4 * D], mod[:, 4 * D:5 * D]
+    ln = torch.nn.functional.layer_norm(x.float(), (D,), w, b, 1e-5)
+    rows = torch.arange(B * S)
+    bi, txt = rows // S, ((rows % S) < n_text)[:, None]
+    ref = ln * (1 + torch.where(txt, sc_t[bi], sc_v[bi])) + torch.where(txt, sh_t[bi], sh_v[bi])
+    mc = mod.to(cuda)
+    out = ops.layernorm_modulate(x.to(cuda), w.to(cuda), b.to(cuda), 1e-5, mc[:, :D], mc[:, D:2 * D], mc[:, 3 * D:4 * D],
+                                 mc[:, 4 * D:5 * D], rows_per_batch=S, n_text=n_text)
+    plain = ops.layernorm_modulate(x.to(cuda), w.to(cuda), b.to(cuda), 1e-5)
+    torch.cuda.synchronize()
+    _bf16_close(out, ref, "ln+mod")
+    _bf16_close(plain, ln, "ln")
+
+
+def test_gemv_and_timestep(cuda, hip_lib):
+    from aether_amd import ops
+    from oracle.dit import timestep_sinusoid
+    g = torch.Generator().manual_seed(1)
+    B, K, N = 2, 3072, 1000
+    x = torch.randn(B, K, generator=g)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g)
+    ref = torch.nn.functional.silu(torch.nn.functional.silu(x) @ W.float().t() + bias)
+    out = ops.gemv_rows(x.to(cuda), W.to(cuda), bias.to(cuda), act_in=1, act_out=1)
+    torch.cuda.synchronize()
+    assert torch.allclose(out.cpu(), ref, rtol=2e-5, atol=2e-5), (out.cpu() - ref).abs().max()   # fp32 in, fp32 out
+    t = torch.tensor([999.0, 19.0])
+    ts = ops.timestep_sinusoid(t.to(cuda), 3072)
+    torch.cuda.synchronize()
+    # fp32 sin/cos of arguments up to 999: one ulp of the argument (6e-5) bounds the difference
+    assert torch.allclose(ts.cpu(), timestep_sinusoid(t, 3072), atol=2e-4, rtol=0)
+
+
+def test_patchify_roundtrip(cuda, hip_lib):
+    from aether_amd import ops
+    g = torch.Generator().manual_seed(2)
+    B, F, Cc, H, W, p = 2, 3, 96, 8, 12, 2
+    x = torch.randn(B, F, Cc, H, W, generator=g).to(torch.bfloat16)
+    A = ops.patchify(x.to(cuda), p)
+    ref = x.reshape(B, F, Cc, H // p, p, W // p, p).permute(0, 1, 3, 5, 2, 4, 6).reshape(B * F * (H // p) * (W // p), Cc * p * p)
+    torch.cuda.synchronize()
+    assert torch.equal(A.cpu(), ref)                      # pure data movement: bit exact
+    # conv2d(k=2,s=2) == patchify @ weight.flatten(1).T
+    wconv = torch.randn(32, Cc, p, p, generator=g)
+    y_conv = torch.nn.functional.conv2d(x.float().reshape(-1, Cc, H, W), wconv, stride=p)
+    y_mat = (ref.float() @ wconv.flatten(1).t()).reshape(B * F, H // p, W // p, 32).permute(0, 3, 1, 2)
+    assert torch.allclose(y_conv, y_mat, atol=1e-4)
+    Cout = 56
+    Y = torch.randn(B * F * (H // p) * (W // p), Cout * p * p, generator=g).to(torch.bfloat16)
+    out = ops.unpatchify(Y.to(cuda), B, F, Cout, H, W, p)
+    ref_out = Y.reshape(B, F, H // p, W // p, -1, p, p).permute(0, 1, 4, 2, 5, 3, 6).flatten(5, 6).flatten(3, 4)
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), ref_out)
+
+
+def _attn_inputs(B, H, S, n_text, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    qkv = (torch.randn(B, S, 3 * H * 64, generator=g) * scale).to(torch.bfloat16)
+    qn_w, kn_w = 1 + 0.1 * torch.randn(64, generator=g), 1 + 0.1 * torch.randn(64, generator=g)
+    qn_b, kn_b = 0.1 * torch.randn(64, generator=g), 0.1 * torch.randn(64, generator=g)
+    ang = torch.rand(S - n_text, 32, generator=g) * 6.28
+    cos, sin = ang.cos().repeat_interleave(2, 1), ang.sin().repeat_interleave(2, 1)
+    return qkv, qn_w, qn_b, kn_w, kn_b, cos, sin
+
+
+def _qk_ref(qkv, H, n_text, qn_w, qn_b, kn_w, kn_b, cos, sin):
+    from oracle.dit import apply_rotary_emb
+    B, S, _ = qkv.shape
+    q, k, v = [t.view(B, S, H, 64).transpose(1, 2) for t in qkv.float().chunk(3, dim=-1)]
+    q = torch.nn.functional.layer_norm(q, (64,), qn_w, qn_b, 1e-6)
+    k = torch.nn.functional.layer_norm(k, (64,), kn_w, kn_b, 1e-6)
+    q = torch.cat([q[:, :, :n_text], apply_rotary_emb(q[:, :, n_text:], cos, sin)], 2)
+    k = torch.cat([k[:, :, :n_text], apply_rotary_emb(k[:, :, n_text:], cos, sin)], 2)
+    return q, k, v
+
+
+@pytest.mark.parametrize("B,H,S,n_text", [(1, 2, 100, 10), (2, 3, 333, 226), (1, 1, 64, 0)])
+def test_qk_norm_rope(cuda, hip_lib, B, H, S, n_text):
+    from aether_amd import ops
+    qkv, qn_w, qn_b, kn_w, kn_b, cos, sin = _attn_inputs(B, H, S, n_text, 11)
+    q, k, v = _qk_ref(qkv, H, n_text, qn_w, qn_b, kn_w, kn_b, cos, sin)
+    c = lambda t: t.to(cuda)
+    Qh, Kh, Vt = ops.qk_norm_rope(c(qkv), H, n_text, c(qn_w), c(qn_b), c(kn_w), c(kn_b), 1e-6, c(cos), c(sin), 0.125)
+    torch.cuda.synchronize()
+    _bf16_close(Qh, q * 0.125, "Qh")
+    _bf16_close(Kh, k, "Kh")
+    assert torch.equal(Vt.cpu()[..., :S].float(), v.transpose(2, 3))      # transpose only: bit exact
+    assert (Vt.cpu()[..., S:] == 0).all()
+
+
+@pytest.mark.parametrize("B,H,S", [(1, 2, 64), (1, 2, 256), (2, 3, 300), (1, 1, 1000), (1, 2, 1541)])
+@pytest.mark.parametrize("flags", [0, 1])
+def test_flash_attention(cuda, hip_lib, B, H, S, flags):
+    from aether_amd import ops
+    g = torch.Generator().manual_seed(S)
+    q = torch.randn(B, H, S, 64, generator=g).to(torch.bfloat16)
+    k = torch.randn(B, H, S, 64, generator=g).to(torch.bfloat16)
+    v = torch.randn(B, H, S, 64, generator=g).to(torch.bfloat16)
+    Spad = (S + 63) // 64 * 64
+    vt = torch.zeros(B, H, 64, Spad, dtype=torch.bfloat16)
+    vt[..., :S] = v.transpose(2, 3)
+    ref = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float(), v.float())    # scale 1/8
+    out = ops.flash_attn_fwd((q.float() * 0.125).to(torch.bfloat16).to(cuda), k.to(cuda), vt.to(cuda), flags=flags)
+    torch.cuda.synchronize()
+    ref = ref.transpose(1, 2).reshape(B, S, H * 64)
+    # P is rounded to bf16 before P·V (as every flash kernel does): 1.5e-2 relative L2, 4 bf16 ulps of the scale
+    _bf16_close(out, ref, f"flash S={S}", rel=1.5e-2, max_ulp_frac=4.0)
+
+
+def test_flash_attention_online_max_jump(cuda, hip_lib):
+    """Force the rescale branch late in the KV sweep: one key far larger than everything before it (guide rule 26)."""
+    from aether_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, H, S = 1, 1, 512
+    q = torch.randn(B, H, S, 64, generator=g)
+    k = torch.randn(B, H, S, 64, generator=g)
+    v = torch.randn(B, H, S, 64, generator=g)
+    k[0, 0, 400] = q[0, 0, 7] * 3.0        # row 7's maximum jumps at KV tile 6
+    k[0, 0, 130] = q[0, 0, 200] * 2.0
+    qb, kb, vb = [t.to(torch.bfloat16) for t in (q * 0.125, k, v)]
+    ref = torch.nn.functional.scaled_dot_product_attention(qb.float(), kb.float(), vb.float(), scale=1.0)
+    vt = vb.transpose(2, 3).contiguous()
+    out = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda))
+    torch.cuda.synchronize()
+    _bf16_close(out, ref.transpose(1, 2).reshape(B, S, 64), "flash max-jump", rel=1.5e-2, max_ulp_frac=4.0)

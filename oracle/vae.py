@@ -332,6 +332,7 @@ class OracleVAE(nn.Module):
 
     @torch.no_grad()
     def encode(self, x):
+        x = x.contiguous()   # CPU bf16 convolutions pick stride-dependent kernels: canonicalise the layout at entry
         H, W = x.shape[-2:]
         if self.use_tiling and (W > self.tile_sample_min_width or H > self.tile_sample_min_height):
             sh = int(self.tile_sample_min_height * (1 - self.tile_overlap_factor_height))
@@ -346,6 +347,7 @@ class OracleVAE(nn.Module):
 
     @torch.no_grad()
     def decode(self, z):
+        z = z.contiguous()
         H, W = z.shape[-2:]
         if self.use_tiling and (W > self.tile_latent_min_width or H > self.tile_latent_min_height):
             sh = int(self.tile_latent_min_height * (1 - self.tile_overlap_factor_height))

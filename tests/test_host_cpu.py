@@ -1,0 +1,149 @@
+"""CPU checks of the host-side pieces against fixtures produced by the REFERENCE itself (tools/make_golden.py imports
+/root/reference in the build container; the .npz files are committed) and against closed-form known answers."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_center_crop_matches_reference_imcrop_center():
+    from aether_amd.preprocess import center_crop_frames
+    z = np.load(os.path.join(GOLD, "imcrop_center.npz"))
+    n = len([k for k in z.files if k.startswith("in_")])
+    assert n >= 7
+    for i in range(n):
+        th, tw = z[f"tgt_{i}"]
+        got = np.stack(center_crop_frames(list(z[f"in_{i}"].astype(np.float32)), int(th), int(tw)))
+        ref = z[f"out_{i}"].astype(np.float32)
+        assert got.shape == ref.shape, i
+        assert np.array_equal(got, ref), i          # pure indexing: bit exact
+
+
+def test_rope_tables_known_answers():
+    """Positions are plain integers at fps 12 (t 0..10, h 0..29, w 0..44), channel split 16|24|24 (P:103-105)."""
+    from aether_amd.rope import resize_crop_region_for_grid, rotary_tables_3d
+    crop = resize_crop_region_for_grid((30, 45), 45, 30)
+    assert crop == ((0, 0), (30, 45))
+    cos, sin = rotary_tables_3d(64, crop, (30, 45), 11, 1.0)
+    assert cos.shape == sin.shape == (14850, 64) and cos.dtype == torch.float32
+    tok = lambda t, h, w: (t * 30 + h) * 45 + w  # noqa: E731
+    i = tok(7, 13, 29)
+    f_t = [10000.0 ** (-2 * k / 16) for k in range(8)]
+    f_hw = [10000.0 ** (-2 * k / 24) for k in range(12)]
+    exp_ang = np.repeat(np.array([7 * f for f in f_t] + [13 * f for f in f_hw] + [29 * f for f in f_hw]), 2)
+    assert np.allclose(cos[i].numpy(), np.cos(exp_ang), atol=2e-6)
+    assert np.allclose(sin[i].numpy(), np.sin(exp_ang), atol=2e-6)
+    # Aether's fps_factor = 12 / fps scales ONLY the temporal positions (P:81-90)
+    cos8, _ = rotary_tables_3d(64, crop, (30, 45), 11, 12 / 8)
+    assert np.allclose(cos8[i, :16].numpy(), np.cos(np.repeat(np.array([7 * 1.5 * f for f in f_t]), 2)), atol=2e-6)
+    assert torch.equal(cos8[:, 16:], cos[:, 16:])
+
+
+def test_rope_matches_oracle_restatement():
+    from aether_amd.rope import resize_crop_region_for_grid, rotary_tables_3d
+    from oracle.rope import prepare_rope
+    for fps, (H, W, F) in [(12, (480, 720, 11)), (24, (480, 720, 5)), (10, (240, 368, 9))]:
+        c0, s0 = prepare_rope(H, W, F, fps)
+        crop = resize_crop_region_for_grid((H // 16, W // 16), 45, 30)
+        c1, s1 = rotary_tables_3d(64, crop, (H // 16, W // 16), F, 12 / fps)
+        assert torch.equal(c0, c1) and torch.equal(s0, s1)
+
+
+def test_scheduler_timesteps_and_schedule():
+    from aether_amd.scheduler import CogVideoXDPMScheduler
+    s = CogVideoXDPMScheduler()
+    s.set_timesteps(50)
+    assert s.timesteps.tolist() == list(range(999, 0, -20))                 # 999, 979, ..., 19 (trailing)
+    s.set_timesteps(4)
+    assert s.timesteps.tolist() == [999, 749, 499, 249]
+    ac = s.alphas_cumprod
+    assert ac.dtype == torch.float64 and ac[-1].item() == 0.0                # zero terminal SNR
+    assert abs(ac[0].item() - (1 - 0.00085)) < 1e-12                         # first value preserved by the rescale
+    assert (ac[1:] < ac[:-1]).all()
+
+
+def _np_dpm_step(ac, n, v, old_x0, t, t_back, x, noise1, noise2):
+    """Independent float64 numpy restatement of the SDE DPM-Solver++(2M) update."""
+    prev_t = t - 1000 // n
+    a_t, a_prev = ac[t], (ac[prev_t] if prev_t >= 0 else np.float64(1.0))
+    x0 = np.sqrt(a_t) * x - np.sqrt(1 - a_t) * v
+    with np.errstate(divide="ignore", invalid="ignore"):
+        lam = lambda a: np.log(np.sqrt(a / (1 - a)))  # noqa: E731
+        h = lam(a_prev) - lam(a_t)
+        m1 = np.sqrt((1 - a_prev) / (1 - a_t)) * np.exp(-h)
+        m2 = np.expm1(-2 * h) * np.sqrt(a_prev)
+        mn = np.sqrt(1 - a_prev) * np.sqrt(1 - np.exp(-2 * h))
+        if old_x0 is None or prev_t < 0:
+            return m1 * x - m2 * x0 + mn * noise1, x0
+        r = (lam(a_t) - lam(ac[t_back])) / h
+        d = (1 + 1 / (2 * r)) * x0 - (1 / (2 * r)) * old_x0
+    return m1 * x - m2 * d + mn * noise2, x0
+
+
+@pytest.mark.parametrize("n", [4, 50])
+def test_scheduler_step_matches_numpy_and_rng_order(n):
+    from aether_amd.scheduler import CogVideoXDPMScheduler
+    s = CogVideoXDPMScheduler()
+    s.set_timesteps(n)
+    ts = s.timesteps.tolist()
+    ac = s.alphas_cumprod.numpy()
+    shape = (1, 3, 8, 4, 6)
+    g = torch.Generator().manual_seed(7)
+    g_ref = torch.Generator().manual_seed(7)
+    x = torch.randn(shape, dtype=torch.float64)
+    x_np, old, old_np = x.numpy().copy(), None, None
+    draws = 0
+    for i, t in enumerate(ts):
+        v = torch.randn(shape, generator=torch.Generator().manual_seed(100 + i), dtype=torch.float64)
+        x, old = s.step(v, old, t, ts[i - 1] if i > 0 else None, x, generator=g)
+        n1 = torch.randn(shape, generator=g_ref, dtype=torch.float64).numpy()
+        two = (old_np is not None) and (t - 1000 // n >= 0)
+        n2 = torch.randn(shape, generator=g_ref, dtype=torch.float64).numpy() if two else None
+        draws += 2 if two else 1
+        x_np, old_np = _np_dpm_step(ac, n, v.numpy(), old_np, t, ts[i - 1] if i > 0 else None, x_np, n1, n2)
+        assert np.allclose(x.numpy(), x_np, rtol=1e-9, atol=1e-9), i
+    assert draws == 1 + 2 * (n - 2) + 1                     # 1 draw on the first and last step, 2 in between
+    # generators in lock-step <=> same number of draws consumed
+    assert torch.equal(torch.randn(4, generator=g), torch.randn(4, generator=g_ref))
+    # last step lands exactly on the predicted clean sample (alpha_prev = 1, no noise)
+    assert np.allclose(x.numpy(), old.numpy())
+
+
+def test_scheduler_dtype_promotion_like_reference():
+    """bf16 latents + fp32 model output -> fp32 prev_sample, noise drawn in the sample's dtype (P:876, P:916)."""
+    from aether_amd.scheduler import CogVideoXDPMScheduler
+    s = CogVideoXDPMScheduler()
+    s.set_timesteps(4)
+    x = torch.randn(1, 2, 4, 4, 4).to(torch.bfloat16)
+    v = torch.randn(1, 2, 4, 4, 4)
+    prev, x0 = s.step(v, None, 999, None, x, generator=torch.Generator().manual_seed(0))
+    assert prev.dtype == torch.float32 and x0.dtype == torch.float32
+    assert torch.isfinite(prev).all()
+
+
+def test_video_processor_roundtrip_and_pil_crop():
+    import PIL.Image
+    from aether_amd.video_processor import VideoProcessor
+    vp = VideoProcessor()
+    frames = np.random.default_rng(0).random((5, 16, 24, 3), dtype=np.float32)
+    t = vp.preprocess(list(frames), 16, 24)
+    assert t.shape == (5, 3, 16, 24) and float(t.min()) >= -1 and float(t.max()) <= 1
+    back = vp.postprocess_video(t.permute(1, 0, 2, 3)[None], output_type="np")
+    assert back.shape == (1, 5, 16, 24, 3) and np.allclose(back[0], frames, atol=1e-6)
+    img = PIL.Image.fromarray((np.random.default_rng(1).random((50, 50, 3)) * 255).astype(np.uint8))
+    out = vp.preprocess(img, 16, 24, resize_mode="crop")
+    assert out.shape == (1, 3, 16, 24)
+
+
+def test_raymap_packing_is_outer_factor():
+    """P:666-670 / P:942-945: latent frame t packs raw frames {t, T+t, 2T+t, 3T+t}; the output un-fold is its inverse."""
+    from einops import rearrange
+    r = torch.arange(44 * 6).reshape(1, 44, 6, 1, 1).float()
+    packed = rearrange(r, "b (n t) c h w -> b t (n c) h w", n=4)
+    assert packed.shape == (1, 11, 24, 1, 1)
+    assert packed[0, 3, :6, 0, 0].tolist() == r[0, 3, :, 0, 0].tolist()
+    assert packed[0, 3, 6:12, 0, 0].tolist() == r[0, 14, :, 0, 0].tolist()
+    assert torch.equal(rearrange(packed, "b t (n c) h w -> b (n t) c h w", n=4), r)

@@ -1,0 +1,112 @@
+"""BASELINE config 1 ("plumbing, no GPU"): the drop-in pipeline end to end on CPU.  The module slots are filled with
+the (depth/width-reduced) fp32 ORACLE transformer and VAE — allowed here because this is a test — and the product
+pipeline's outputs are compared, bit for bit, with oracle/pipeline.py's straight-line restatement of the reference's
+`__call__` on the same seed.  Also pins the error strings of check_inputs (they are API, P:362-449)."""
+import numpy as np
+import pytest
+import torch
+
+H, W, F = 96, 240, 17   # scaled-down 480x720: tiles 48x120, strides 40x96, latent 12x30 (tiling composes exactly)
+
+
+@pytest.fixture(scope="module")
+def parts():
+    from aether_amd.scheduler import CogVideoXDPMScheduler
+    from oracle.dit import DitConfig, OracleTransformer3D, init_random_ as init_dit
+    from oracle.vae import OracleVAE, VaeConfig, init_random_ as init_vae
+    torch.manual_seed(0)
+    tcfg = DitConfig(num_attention_heads=2, num_layers=1, text_embed_dim=64, time_embed_dim=32, max_text_seq_length=8,
+                     sample_width=W // 8, sample_height=H // 8, sample_frames=F)
+    dit = init_dit(OracleTransformer3D(tcfg), seed=1).to(torch.bfloat16)
+    vcfg = VaeConfig(block_out_channels=(32, 64, 64, 64), layers_per_block=1, sample_height=H, sample_width=W)
+    vae = init_vae(OracleVAE(vcfg), seed=2).to(torch.bfloat16)
+    vae.enable_tiling()
+    vae.enable_slicing()
+    prompt = (torch.randn(1, 8, 64) * 0.1).to(torch.bfloat16)
+    return dit, vae, CogVideoXDPMScheduler, prompt
+
+
+def _pipe(parts):
+    from aether.pipelines.aetherv1_pipeline_cogvideox import AetherV1PipelineCogVideoX
+    dit, vae, Sched, prompt = parts
+    p = AetherV1PipelineCogVideoX(tokenizer=None, text_encoder=None, vae=vae, scheduler=Sched(), transformer=dit,
+                                  empty_prompt_embeds=prompt)
+    p.set_progress_bar_config(disable=True)
+    return p
+
+
+def _video():
+    g = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:H, 0:W]
+    return np.stack([np.stack([0.5 + 0.5 * np.sin(0.1 * xx + 0.2 * t + c) * np.cos(0.07 * yy) for c in range(3)], -1)
+                     for t in range(F)]).astype(np.float32) * 0.9 + 0.05 * g.random((F, H, W, 3), dtype=np.float32)
+
+
+def _oracle_run(parts, task, **kw):
+    from aether_amd.rope import resize_crop_region_for_grid, rotary_tables_3d
+    from oracle.pipeline import sample
+    dit, vae, Sched, prompt = parts
+    rope = rotary_tables_3d(64, resize_crop_region_for_grid((H // 16, W // 16), W // 16, H // 16), (H // 16, W // 16), (F - 1) // 4 + 1, 1.0)
+    return sample(task, dit, vae, Sched(), prompt, height=H, width=W, num_frames=F, rope=rope, **kw)
+
+
+def test_reconstruction_matches_straight_line_oracle(parts):
+    pipe = _pipe(parts)
+    video = _video()
+    out = pipe(task="reconstruction", video=video, height=H, width=W, num_frames=F, fps=12,
+               generator=torch.Generator().manual_seed(42))
+    assert out.rgb.shape == (F, H, W, 3) and out.disparity.shape == (F, H, W) and out.raymap.shape == (F, 6, H // 8, W // 8)
+    assert out.rgb.dtype == np.float32 and 0 <= out.rgb.min() and out.rgb.max() <= 1
+    v = torch.from_numpy(video).permute(0, 3, 1, 2) * 2 - 1
+    rgb, disp, rm = _oracle_run(parts, "reconstruction", video=v, generator=torch.Generator().manual_seed(42))
+    assert np.array_equal(out.rgb, rgb.numpy()) and np.array_equal(out.disparity, disp.numpy()) and np.array_equal(out.raymap, rm.numpy())
+    again = pipe(task="reconstruction", video=video, height=H, width=W, num_frames=F, generator=torch.Generator().manual_seed(42))
+    assert np.array_equal(out.rgb, again.rgb)                      # seeded -> reproducible
+    other = pipe(task="reconstruction", video=video, height=H, width=W, num_frames=F, generator=torch.Generator().manual_seed(43))
+    assert not np.array_equal(out.rgb, other.rgb)
+
+
+@pytest.mark.parametrize("task", ["prediction", "planning"])
+def test_cfg_tasks_match_straight_line_oracle(parts, task):
+    pipe = _pipe(parts)
+    img, goal = _video()[0], _video()[-1]
+    raymap = np.random.default_rng(5).standard_normal((F, 6, H // 8, W // 8)).astype(np.float32)
+    kw = dict(image=img, raymap=raymap, goal=goal if task == "planning" else None)
+    out = pipe(task=task, height=H, width=W, num_frames=F, num_inference_steps=3, fps=12, generator=torch.Generator().manual_seed(1), **kw)
+    t = lambda a: torch.from_numpy(a).permute(2, 0, 1)[None] * 2 - 1  # noqa: E731
+    rgb, disp, rm = _oracle_run(parts, task, image=t(img), goal=t(goal) if task == "planning" else None,
+                                raymap=torch.from_numpy(raymap)[None], num_inference_steps=3,
+                                generator=torch.Generator().manual_seed(1))
+    assert np.array_equal(out.rgb, rgb.numpy()) and np.array_equal(out.disparity, disp.numpy()) and np.array_equal(out.raymap, rm.numpy())
+
+
+def test_task_inference_and_defaults(parts):
+    pipe = _pipe(parts)
+    assert pipe._default_num_inference_steps == {"reconstruction": 4, "prediction": 50, "planning": 50}
+    assert pipe._default_guidance_scale == {"reconstruction": 1.0, "prediction": 3.0, "planning": 3.0}
+    assert pipe._supported_tasks == ["reconstruction", "prediction", "planning"] and pipe._base_fps == 12
+    assert pipe.vae_scale_factor_spatial == 8 and pipe.vae_scale_factor_temporal == 4 and pipe.vae_scaling_factor_image == 0.7
+
+
+def test_check_inputs_messages(parts):
+    pipe = _pipe(parts)
+    img = _video()[0]
+    cases = [
+        (dict(task="foo", image=img), "`task` has to be one of ['reconstruction', 'prediction', 'planning']."),
+        (dict(task="prediction"), "`image` or `video` has to be provided."),
+        (dict(task="prediction", image=img, video=_video()), "`image` and `video` cannot both be provided."),
+        (dict(task="reconstruction", image=img), "`image` is not supported for `reconstruction` task."),
+        (dict(task="prediction", image=img, goal=img), "`goal` is only supported for `planning` task."),
+        (dict(task="prediction", video=_video()), "`video` is only supported for `reconstruction` task."),
+        (dict(task="prediction", image=img, height=60), "`height` and `width` have to be divisible by 8 but are 60 and 240."),
+        (dict(task="prediction", image=img, num_frames=16), "`num_frames` has to be one of [17, 25, 33, 41]."),
+        (dict(task="prediction", image=img, fps=30), "`fps` has to be one of [8, 10, 12, 15, 24]."),
+        (dict(task="prediction", image=img, raymap="x"), "`raymap` has to be of type `torch.Tensor` or `np.ndarray`."),
+    ]
+    for kw, msg in cases:
+        kw.setdefault("height", H); kw.setdefault("width", W); kw.setdefault("num_frames", F)
+        with pytest.raises(ValueError) as e:
+            pipe(**kw)
+        assert str(e.value) == msg, (kw.keys(), str(e.value))
+    with pytest.raises(ValueError, match="`raymap` shape is not correct"):
+        pipe(task="prediction", image=img, raymap=np.zeros((F, 6, 4, 4), np.float32), height=H, width=W, num_frames=F)

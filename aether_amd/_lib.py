@@ -42,6 +42,12 @@ SIGNATURES = {
     "aether_unpatchify": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "aether_qk_norm_rope": (_i, [_vp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _f, _fp, _fp, _f, _vp, _vp, _vp, _i, _vp]),
     "aether_flash_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "aether_conv_gemm_bf16": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _fp, _vp, _i, _i, _vp]),
+    "aether_im2col_first": (_i, [_vp, C.c_long, C.c_long, C.c_long, C.c_long, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "aether_groupnorm_stats": (_i, [_vp, _i, _i, _i, _i, _f, _fp, _i, _fp, _vp]),
+    "aether_groupnorm_apply": (_i, [_vp, _i, _i, _i, _i, _i, _i, _fp, _fp, _fp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i,
+                                    _fp, _fp, _fp, _fp, C.POINTER(C.c_int), _vp]),
+    "aether_resample_pad": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "aether_dit_create": (_vp, [C.POINTER(AetherDitConfig)]),
     "aether_dit_destroy": (None, [_vp]),
     "aether_dit_set_weight": (_i, [_vp, C.c_char_p, _vp]),

@@ -1,0 +1,227 @@
+// Templated bf16 MFMA GEMM main loop shared by the DiT linears (gemm_bf16.hip) and the VAE's implicit-GEMM
+// convolutions (vae_conv.hip):   C[M,N] = epi( A[M,K] · W[N,K]^T ),  fp32 accumulate on v_mfma_f32_32x32x16_bf16.
+//
+// Geometry: 8 wavefronts as WM (along M) x WN (along N); each wave owns (MT*32) x (NT*32) outputs;
+//   workgroup tile BM = WM*MT*32, BN = WN*NT*32, BK = 64.  Instantiations:
+//     <2,4,4,2>  256x256  (DiT linears; N a multiple of 256)
+//     <4,2,4,2>  512x128  (VAE 128-channel layers; uses all 160 KiB of LDS)
+//     <8,1,2,1>  512x32   (VAE conv_out: 32 / 3(+pad) output channels)
+// The MFMA is issued "swapped" (W fragment = A operand) so a lane owns 4 consecutive output columns of one row.
+// Operand tiles: 16-byte LDS-DMA, double buffered, one barrier per K tile, 128-byte LDS rows XOR-swizzled
+// (16-B chunk ^= (row>>1)&7 on the DMA source address and on the ds_read_b128 address).
+//
+// A-row addressing is a policy:
+//   linear:   row m starts at A + m*lda,                       K step kt adds kt*64 elements
+//   gathered: row m starts at A + voxel_offset(m) (a zero-padded channels-last activation volume) and K step kt
+//             adds tap_off[kt] elements — the (dt,dh,dw) tap and 64-channel block of an implicit-GEMM convolution.
+#pragma once
+#include "common.hpp"
+
+namespace aether {
+
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_GATE_RES = 2 };
+
+struct GemmArgs {
+    const bf16_t* A; int lda;
+    const bf16_t* W; int ldw;
+    bf16_t* C; int ldc;
+    int M, N, K;
+    const float* bias;          // [N] fp32 or null
+    const bf16_t* R; int ldr;   // residual / additive term [M,N] or null
+    const float* gate_vid;      // fp32 gate for video rows (index b*gate_bstride + n) or null (=1)
+    const float* gate_txt;      // fp32 gate for text rows
+    int gate_bstride;
+    int rows_per_batch;         // S  (batch index of row m is m / S)
+    int n_text;                 // rows [0, n_text) of each batch are text rows
+    int tiles_m, tiles_n;
+    // gathered-A (implicit-GEMM convolution) only:
+    const int* tap_off;         // [K/64] element offsets added per K step
+    int oT, oH, oW;             // output volume per batch item: M = NB*oT*oH*oW, row m = ((nb*oT+t)*oH+h)*oW+w
+    int iT, iH, iW, iC;         // padded input volume dims (frames, rows, cols, channels per voxel)
+    int stride_hw;              // spatial stride (1, or 2 for the down-sampling conv2d)
+};
+
+constexpr int GEMM_BK = 64;
+constexpr int GEMM_GROUP_M = 4;
+
+template <int WM, int WN, int MT, int NT, int EPI, bool WIDE_STORE, bool GATHER>
+__global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
+    static_assert(WM * WN == 8, "8 wavefronts per workgroup");
+    constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+    constexpr int A_TILE = BM * GEMM_BK * 2, W_TILE = BN * GEMM_BK * 2, BUF_BYTES = A_TILE + W_TILE;
+    constexpr int A_ROUNDS = BM / 64;
+    constexpr int W_ROUNDS = (BN + 63) / 64;
+    static_assert(2 * BUF_BYTES <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const int hi = lane >> 5;
+    const int l32 = lane & 31;
+
+    // ---- tile assignment: XCD-aware remap, then groups of GEMM_GROUP_M row tiles x all column tiles ------------
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int wgid = xcd_remap(blockIdx.x, nwg);
+    const int per_group = GEMM_GROUP_M * p.tiles_n;
+    const int group = wgid / per_group;
+    const int first_m = group * GEMM_GROUP_M;
+    const int gsz = min(GEMM_GROUP_M, p.tiles_m - first_m);
+    const int in_group = wgid - group * per_group;
+    const int tile_m = first_m + in_group % gsz;
+    const int tile_n = in_group / gsz;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- staging addresses ---------------------------------------------------------------------------------------
+    // One wave-instruction moves 8 rows x 128 B; round r covers tile rows r*64 + wave*8 + lane/8.
+    const int srow = wave * 8 + (lane >> 3);
+    const int schunk = (lane & 7) ^ ((srow >> 1) & 7);
+    unsigned a_off[A_ROUNDS], w_off[W_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < A_ROUNDS; ++r) {
+        const int am = min(m0 + r * 64 + srow, p.M - 1);
+        if (GATHER) {
+            int w = am % p.oW; int q = am / p.oW;
+            int h = q % p.oH; q /= p.oH;            // q = nb*oT + t  (front padding is part of iT)
+            const int nb = q / p.oT, t = q - nb * p.oT;
+            a_off[r] = (unsigned)((((size_t)nb * p.iT + t) * p.iH + (size_t)h * p.stride_hw) * p.iW + (size_t)w * p.stride_hw) * (unsigned)p.iC + schunk * 8;
+        } else {
+            a_off[r] = (unsigned)am * (unsigned)p.lda + schunk * 8;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < W_ROUNDS; ++r) {
+        const int wr = min(n0 + r * 64 + srow, p.N - 1);
+        w_off[r] = (unsigned)wr * (unsigned)p.ldw + schunk * 8;
+    }
+    char* const lds_stage = smem + wave * 1024;
+    const bool w_active = (BN >= 64) || (srow < BN);   // BN = 32: only half of the threads carry weight rows
+
+    auto stage = [&](int kt, int buf) {
+        const bf16_t* Ak = p.A + (GATHER ? p.tap_off[kt] : kt * GEMM_BK);
+        const bf16_t* Wk = p.W + kt * GEMM_BK;
+        char* dst = lds_stage + buf * BUF_BYTES;
+#pragma unroll
+        for (int r = 0; r < A_ROUNDS; ++r) glds16(Ak + a_off[r], dst + r * 8192);
+        if (w_active) {
+#pragma unroll
+            for (int r = 0; r < W_ROUNDS; ++r) glds16(Wk + w_off[r], dst + A_TILE + r * 8192);
+        }
+    };
+
+    // ---- fragment read addresses -----------------------------------------------------------------------------------
+    const int swz = (lane >> 1) & 7;
+    const int x_row_base = (wm * MT * 32 + l32) * 128;
+    const int w_row_base = A_TILE + (wn * NT * 32 + l32) * 128;
+    int chunk_off[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) chunk_off[ks] = (((2 * ks + hi) ^ swz) << 4);
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+
+    const int nk = p.K / GEMM_BK;
+    stage(0, 0);
+    drain_and_barrier();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+        const char* base = smem + cur * BUF_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 wf[NT], xf[MT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wf[nt] = *(const bf16x8*)(base + w_row_base + nt * 4096 + chunk_off[ks]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) xf[mt] = *(const bf16x8*)(base + x_row_base + mt * 4096 + chunk_off[ks]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
+        }
+        drain_and_barrier();
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------------------
+    // acc[mt][nt][r] = C[m][n], m = m0 + (wm*MT + mt)*32 + l32,  n = n0 + (wn*NT + nt)*32 + 8*(r>>2) + 4*hi + (r&3)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + (wm * MT + mt) * 32 + l32;
+        const bool m_ok = m < p.M;
+        const float* gate = nullptr;
+        if (EPI == EPI_BIAS_GATE_RES && p.gate_vid != nullptr) {
+            const int mm = m_ok ? m : 0;
+            const int b = mm / p.rows_per_batch;
+            const int t = mm - b * p.rows_per_batch;
+            gate = (t < p.n_text ? p.gate_txt : p.gate_vid) + (size_t)b * p.gate_bstride;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int nbase = n0 + (wn * NT + nt) * 32;   // N % 32 == 0: a 32-column group is all in or all out
+            if (nbase >= p.N) continue;                   // wave-uniform
+            unsigned pk[4][2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = nbase + 8 * g + 4 * hi;
+                float v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = acc[mt][nt][4 * g + c];
+                if (p.bias != nullptr) {
+                    const f32x4 bv = *(const f32x4*)(p.bias + n);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] += bv[c];
+                }
+                if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = gelu_tanh(v[c]);
+                }
+                if (EPI == EPI_BIAS_GATE_RES) {
+                    if (gate != nullptr) {
+                        const f32x4 gv = *(const f32x4*)(gate + n);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] *= gv[c];
+                    }
+                    if (p.R != nullptr) {
+                        u16x4 rv = {0, 0, 0, 0};
+                        if (m_ok) rv = *(const u16x4*)(p.R + (size_t)m * p.ldr + n);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] += bf16_bits_to_f32(rv[c]);
+                    }
+                }
+                pk[g][0] = pack_bf16x2(v[0], v[1]);
+                pk[g][1] = pack_bf16x2(v[2], v[3]);
+            }
+            if (WIDE_STORE) {
+                // half-wave exchange: lanes 0-31 end with columns 8g..8g+7, lanes 32-63 with 8(g+1)..8(g+1)+7
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    auto r0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
+                    auto r1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
+                    if (m_ok) {
+                        uint4 o = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                        *(uint4*)(p.C + (size_t)m * p.ldc + nbase + 8 * g + 8 * hi) = o;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (m_ok) {
+                        uint2 o = make_uint2(pk[g][0], pk[g][1]);
+                        *(uint2*)(p.C + (size_t)m * p.ldc + nbase + 8 * g + 4 * hi) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace aether

@@ -103,6 +103,49 @@ int aether_flash_attn_fwd(const void* Qh, const void* Kh, const void* Vt, void* 
                           int flags, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * 3D-causal VAE kernels (diffusers AutoencoderKLCogVideoX: encode at P:557-618, decode_latents at P:931,936).
+ * Activations are channels-last volumes [NB, T, H, W, C] bf16, NB = spatial tiles batched together.
+ * Convolution inputs are zero-bordered volumes that already contain the causal front frames.
+ * ------------------------------------------------------------------------------------------------ */
+
+/* Implicit-GEMM convolution: out[M = NB*oT*oH*oW, Cout] = bias + R + sum over taps of X(voxel + tap) · Wᵀ.
+ * Replaces CogVideoXCausalConv3d.conv (3x3x3, input volume [NB, oT+2, oH+2, oW+2, iC]), the resamplers' Conv2d
+ * (3x3 stride 1 on [NB, oT, oH+2, oW+2, iC]; 3x3 stride 2 on [NB, oT, 2*oH+1, 2*oW+1, iC]) and conv_shortcut (1x1x1).
+ * tap_off: device int32 [n_taps], element offset of K step k inside the padded volume (tap base + 64*channel block);
+ * W bf16 [Cout, n_taps*64] with the matching K order (tap-major, then channel); iC % 64 == 0; Cout % 32 == 0.
+ * R (bf16 [M, Cout], ldr) is added when non-NULL (ResNet skip). */
+int aether_conv_gemm_bf16(const void* X, int NB, int iT, int iH, int iW, int iC, int oT, int oH, int oW, int stride_hw,
+                          const int* tap_off, int n_taps, const void* W, int Cout, void* C, int ldc, const float* bias,
+                          const void* R, int ldr, int flags, void* stream);
+
+/* Explicit im2col for the thin first convolutions (encoder conv_in 3->128, decoder conv_in 16->512):
+ * x is a strided [Cin, T_all, H_all, W_all] tensor (element strides sC,sT,sH,sW); the crop starts at frame t0,
+ * row y0, column x0 and spans T x H x W; zero padding at the crop border; causal front = the two frames before t0
+ * (first_chunk != 0: the crop's first frame replicated).  A bf16 [T*H*W, Kpad], column ((dt*3+dh)*3+dw)*Cin + c. */
+int aether_im2col_first(const void* x, long sC, long sT, long sH, long sW, int Cin, int t0, int first_chunk, int y0, int x0,
+                        int T, int H, int W, void* A, int Kpad, void* stream);
+
+/* GroupNorm statistics of x [NB, V, C] -> stats fp32 [NB, G, 2] = (mean, rstd).  Deterministic: per-block
+ * per-channel partial sums (partial_ws fp32 [NB, nblk, 2, C]) merged in double with the parallel-variance formula. */
+int aether_groupnorm_stats(const void* x, int NB, int V, int C, int G, float eps, float* partial_ws, int nblk, float* stats,
+                           void* stream);
+
+/* y = [silu]( GN(x)·gamma+beta  [· (Wy·zq+by) + (Wb·zq+bb)] ) written at interior offset (pt,ph,pw) of the
+ * zero-bordered volume y [NB, oT, oH, oW, C].  zq != NULL selects CogVideoXSpatialNorm3D: zq is the latent
+ * [NB, zT, zH, zW, zC<=16] channels-last, nearest-resized (tmap_host[t] = source latent frame of frame t, host
+ * array of T ints; H % zH == 0, W % zW == 0); wy,wb fp32 [C, zC]; by,bb fp32 [C]. */
+int aether_groupnorm_apply(const void* x, int NB, int T, int H, int W, int C, int G, const float* stats, const float* gamma,
+                           const float* beta, int silu_flag, void* y, int oT, int oH, int oW, int pt, int ph, int pw,
+                           const void* zq, int zT, int zH, int zW, int zC, const float* wy, const float* by, const float* wb,
+                           const float* bb, const int* tmap_host, void* stream);
+
+/* Resample x [NB,T,H,W,C] into a zero-bordered volume y [NB,oT,oH,oW,C] at interior offset (pt,ph,pw).
+ * mode 0 copy; 1 temporal avg-pool k2 s2 (first frame kept when T is odd; CogVideoXDownsample3D);
+ * 2 nearest x2 in space; 3 nearest x2 in space and time with the first-frame rule of CogVideoXUpsample3D. */
+int aether_resample_pad(const void* x, int NB, int T, int H, int W, int C, int mode, void* y, int oT, int oH, int oW, int pt,
+                        int ph, int pw, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Whole-transformer entry (one call = CogVideoXTransformer3DModel.forward as invoked at P:865-875)
  * ------------------------------------------------------------------------------------------------ */
 typedef struct AetherDitConfig {

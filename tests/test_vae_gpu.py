@@ -1,0 +1,235 @@
+"""VAE parity on MI355X: each HIP kernel against an fp32 PyTorch evaluation of the same operator, then the whole native
+encoder / decoder (tiled + frame-batched, as the reference runs it, D:229-230) against the fp32 CPU oracle with a
+tolerance calibrated by the bf16 run of the oracle itself."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-12)).item()
+
+
+def _vae(cuda):
+    from aether_amd.vae import AetherVAE
+    return AetherVAE({"block_out_channels": (64, 128, 128, 128), "layers_per_block": 1, "sample_height": 96, "sample_width": 240}, device=cuda)
+
+
+@pytest.mark.parametrize("cin,cout,kt", [(64, 256, 3), (128, 128, 3), (64, 32, 3), (64, 64, 1)])
+def test_conv_gemm_vs_conv3d(cuda, hip_lib, cin, cout, kt):
+    """3x3x3 causal conv (kt=3) and 3x3 conv2d (kt=1) on a zero-bordered channels-last volume."""
+    from aether_amd.vae import _Conv
+    g = torch.Generator().manual_seed(cin + cout)
+    NB, T, H, W = 2, 3, 10, 13
+    x = torch.randn(NB, cin, T + kt - 1, H, W, generator=g).to(torch.bfloat16)         # already causally padded in time
+    w = (torch.randn(cout, cin, kt, 3, 3, generator=g) / (cin * 9 * kt) ** 0.5).to(torch.bfloat16)
+    b = torch.randn(cout, generator=g)
+    res = torch.randn(NB, T, H, W, cout, generator=g).to(torch.bfloat16)
+    ref = F.conv3d(x.float(), w.float(), b, padding=(0, 1, 1)).permute(0, 2, 3, 4, 1) + res.float()
+    vae = _vae(cuda)
+    conv = _Conv(w if kt == 3 else w[:, :, 0], b, cuda)
+    vol = torch.zeros(NB, T + kt - 1, H + 2, W + 2, cin, dtype=torch.bfloat16, device=cuda)
+    vol[:, :, 1:-1, 1:-1] = x.permute(0, 2, 3, 4, 1).to(cuda)
+    out = vae._conv(vol, conv, (T, H, W), 1, res.to(cuda))
+    torch.cuda.synchronize()
+    assert _rel(out[..., :cout].cpu(), ref) < 6e-3
+
+
+def test_conv_stride2_vs_conv2d(cuda, hip_lib):
+    from aether_amd.vae import _Conv
+    g = torch.Generator().manual_seed(9)
+    NB, T, H, W, Cc = 1, 2, 12, 16, 64
+    x = torch.randn(NB * T, Cc, H, W, generator=g).to(torch.bfloat16)
+    w = (torch.randn(Cc, Cc, 3, 3, generator=g) / (Cc * 9) ** 0.5).to(torch.bfloat16)
+    b = torch.randn(Cc, generator=g)
+    ref = F.conv2d(F.pad(x.float(), (0, 1, 0, 1)), w.float(), b, stride=2).reshape(NB, T, Cc, H // 2, W // 2).permute(0, 1, 3, 4, 2)
+    vae = _vae(cuda)
+    xs = x.reshape(NB, T, Cc, H, W).permute(0, 1, 3, 4, 2).contiguous().to(cuda)
+    vol = vae._resample(xs, 0, (NB, T, H + 1, W + 1, Cc), (0, 0, 0))
+    out = vae._conv(vol, _Conv(w, b, cuda), (T, H // 2, W // 2), stride=2)
+    torch.cuda.synchronize()
+    assert _rel(out.cpu(), ref) < 6e-3
+
+
+@pytest.mark.parametrize("T", [1, 2, 5, 8])
+def test_resamplers_match_oracle(cuda, hip_lib, T):
+    from oracle.vae import Downsample3D, Upsample3D
+    g = torch.Generator().manual_seed(T)
+    NB, H, W, Cc = 2, 6, 8, 64
+    x = torch.randn(NB, Cc, T, H, W, generator=g).to(torch.bfloat16)
+    xs = x.permute(0, 2, 3, 4, 1).contiguous().to(cuda)
+    vae = _vae(cuda)
+    # temporal average pool (the part of CogVideoXDownsample3D before the conv)
+    ds = Downsample3D(Cc, True)
+    xp = x.float().permute(0, 3, 4, 1, 2).reshape(NB * H * W, Cc, T)
+    if T % 2 == 1:
+        rest = F.avg_pool1d(xp[..., 1:], 2, 2) if T > 1 else xp[..., 1:]
+        ref = torch.cat([xp[..., :1], rest], -1)
+    else:
+        ref = F.avg_pool1d(xp, 2, 2)
+    Tn = ref.shape[-1]
+    ref = ref.reshape(NB, H, W, Cc, Tn).permute(0, 4, 1, 2, 3)
+    vol = vae._resample(xs, 1, (NB, Tn, H + 1, W + 1, Cc), (0, 0, 0))
+    torch.cuda.synchronize()
+    assert _rel(vol[:, :, :H, :W].cpu(), ref) < 3e-3 and float(vol[:, :, H].abs().max()) == 0 and float(vol[:, :, :, W].abs().max()) == 0
+    # nearest up-sampling with the first-frame rule (the part of CogVideoXUpsample3D before the conv)
+    up = Upsample3D(Cc, True)
+    up.conv = torch.nn.Identity()
+    ref_up = up(x.float()).permute(0, 2, 3, 4, 1)
+    Tu = ref_up.shape[1]
+    vol = vae._resample(xs, 3, (NB, Tu, 2 * H + 2, 2 * W + 2, Cc), (0, 1, 1))
+    torch.cuda.synchronize()
+    assert torch.equal(vol[:, :, 1:-1, 1:-1].cpu().float(), ref_up)
+    _ = ds
+
+
+@pytest.mark.parametrize("Cc,T", [(64, 3), (128, 2), (512, 5)])
+def test_groupnorm_silu_and_spatial_norm(cuda, hip_lib, Cc, T):
+    from aether_amd.vae import _Norm
+    from oracle.vae import SpatialNorm3D
+    g = torch.Generator().manual_seed(Cc)
+    NB, H, W = 2, 8, 12
+    x = (torch.randn(NB, Cc, T, H, W, generator=g) * 2 + 0.3).to(torch.bfloat16)
+    xs = x.permute(0, 2, 3, 4, 1).contiguous().to(cuda)
+    vae = _vae(cuda)
+    gn = torch.nn.GroupNorm(32, Cc, eps=1e-6)
+    with torch.no_grad():
+        gn.weight.copy_(1 + 0.1 * torch.randn(Cc, generator=g)); gn.bias.copy_(0.1 * torch.randn(Cc, generator=g))
+    ref = F.silu(gn(x.float())).permute(0, 2, 3, 4, 1)
+    n = _Norm({"w.weight": gn.weight, "w.bias": gn.bias}, "w.", cuda, False)
+    vol = vae._norm_to_padded(xs, n, 2, 1, True)
+    torch.cuda.synchronize()
+    assert _rel(vol[:, 2:, 1:-1, 1:-1].cpu(), ref) < 5e-3
+    assert float(vol[:, :, 0].abs().max()) == 0 and float(vol[:, :, :, -1].abs().max()) == 0      # borders stay zero
+    # SpatialNorm3D with a nearest-resized latent (odd T > 1 exercises the first-frame rule)
+    zT = {3: 3, 2: 2, 5: 3}[T]
+    zq = torch.randn(NB, 16, zT, H // 4, W // 4, generator=g).to(torch.bfloat16)
+    sn = SpatialNorm3D(Cc, 16, 32)
+    with torch.no_grad():
+        for name, p in sn.named_parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.3 if p.dim() > 1 else 0.1))
+        sn.norm_layer.weight.add_(1.0)
+    ref = F.silu(sn(x.float(), zq.float())).permute(0, 2, 3, 4, 1)
+    sd = {"s." + k: v for k, v in sn.state_dict().items()}
+    n = _Norm(sd, "s.", cuda, True)
+    vol = vae._norm_to_padded(xs, n, 2, 1, True, zq.permute(0, 2, 3, 4, 1).contiguous().to(cuda))
+    torch.cuda.synchronize()
+    assert _rel(vol[:, 2:, 1:-1, 1:-1].cpu(), ref) < 5e-3
+
+
+def test_im2col_first_matches_unfold(cuda, hip_lib):
+    from aether_amd.vae import _Conv
+    g = torch.Generator().manual_seed(4)
+    Cc, Tall, Hall, Wall = 3, 7, 20, 24
+    x = torch.randn(Cc, Tall, Hall, Wall, generator=g).to(torch.bfloat16)
+    w = torch.randn(32, Cc, 3, 3, 3, generator=g).to(torch.bfloat16)
+    conv = _Conv(w, torch.zeros(32), cuda, pad_k_to=128)
+    vae = _vae(cuda)
+    for (t0, T, first) in [(0, 3, True), (3, 4, False)]:
+        y0, x0, H, W = 4, 8, 10, 12
+        A = vae._im2col(x.to(cuda), conv, [(y0, x0)], t0, T, H, W, first)
+        crop = x[:, :, y0:y0 + H, x0:x0 + W].float()
+        front = crop[:, :1].repeat(1, 2, 1, 1) if first else crop[:, t0 - 2:t0]
+        vol = torch.cat([front, crop[:, t0:t0 + T]], 1)[None]
+        ref = F.conv3d(vol, w.float(), padding=(0, 1, 1))[0].permute(1, 2, 3, 0).reshape(T * H * W, 32)
+        got = A[0].float().cpu() @ conv.w.float().cpu().t()
+        torch.cuda.synchronize()
+        assert torch.allclose(got, ref, atol=2e-2, rtol=2e-2)
+        assert float(A[0, :, 81:].abs().max()) == 0
+
+
+def _oracle_pair(cfg_kw, seed=0):
+    from oracle.vae import OracleVAE, VaeConfig, init_random_
+    cfg = VaeConfig(**cfg_kw)
+    o32 = init_random_(OracleVAE(cfg), seed)
+    sd = {k: v.to(torch.bfloat16) for k, v in o32.state_dict().items()}
+    o32.load_state_dict({k: v.float() for k, v in sd.items()})
+    o16 = OracleVAE(cfg).to(torch.bfloat16)
+    o16.load_state_dict(sd)
+    for o in (o32, o16):
+        o.enable_tiling()
+    return cfg, sd, o32, o16
+
+
+def _smooth_video(T, H, W, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij")
+    frames = [torch.stack([torch.sin(0.09 * xx + 0.3 * t + c) * torch.cos(0.06 * yy - 0.1 * t) for c in range(3)]) for t in range(T)]
+    v = torch.stack(frames, 1) * 0.8 + 0.1 * torch.randn(3, T, H, W, generator=g)
+    return v.clamp(-1, 1)[None].to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("T", [1, 17])
+def test_vae_encode_small_tiled(cuda, hip_lib, T):
+    from aether_amd.vae import AetherVAE
+    kw = dict(block_out_channels=(64, 128, 128, 128), layers_per_block=1, sample_height=96, sample_width=240)
+    cfg, sd, o32, o16 = _oracle_pair(kw)
+    x = _smooth_video(T, 96, 240)
+    ref = o32.encode(x.float()).latent_dist.parameters
+    ref16 = o16.encode(x).latent_dist.parameters
+    vae = AetherVAE(kw, device=cuda).load_state_dict(sd)
+    vae.enable_tiling(); vae.enable_slicing()
+    got = vae.encode(x.to(cuda)).latent_dist.parameters
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape == (1, 32, (T - 1) // 4 + 1, 12, 30)
+    e_n, e_16 = _rel(got.cpu(), ref), _rel(ref16, ref)
+    print(f"encode T={T}: native {e_n:.3e}  bf16-oracle {e_16:.3e}")
+    assert e_n < 1.5 * e_16 + 3e-3
+
+
+def test_vae_decode_small_tiled_and_posterior_rng(cuda, hip_lib):
+    from aether_amd.vae import AetherVAE
+    kw = dict(block_out_channels=(64, 128, 128, 128), layers_per_block=1, sample_height=96, sample_width=240)
+    cfg, sd, o32, o16 = _oracle_pair(kw, seed=1)
+    z = (torch.randn(1, 16, 5, 12, 30, generator=torch.Generator().manual_seed(3))).to(torch.bfloat16)
+    ref = o32.decode(z.float()).sample
+    ref16 = o16.decode(z).sample
+    vae = AetherVAE(kw, device=cuda).load_state_dict(sd)
+    vae.enable_tiling()
+    got = vae.decode(z.to(cuda)).sample
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape == (1, 3, 17, 96, 240)
+    e_n, e_16 = _rel(got.cpu(), ref), _rel(ref16, ref)
+    print(f"decode: native {e_n:.3e}  bf16-oracle {e_16:.3e}")
+    assert e_n < 1.5 * e_16 + 3e-3
+    # untiled path too
+    vae.disable_tiling(); o32.use_tiling = False
+    assert _rel(vae.decode(z.to(cuda)).sample.cpu(), o32.decode(z.float()).sample) < 1.5 * e_16 + 3e-3
+    # posterior sample draws randn(mean.shape) in bf16 from the caller's generator
+    vae.enable_tiling()
+    x = _smooth_video(5, 96, 240)
+    post = vae.encode(x.to(cuda)).latent_dist
+    gen = torch.Generator(device=cuda).manual_seed(5)
+    s = post.sample(gen)
+    noise = torch.randn(post.mean.shape, generator=torch.Generator(device=cuda).manual_seed(5), device=cuda, dtype=torch.bfloat16)
+    assert torch.equal(s, post.mean + post.std * noise)
+
+
+def test_vae_full_width_decode_chunk(cuda, hip_lib):
+    """Real channel widths (128,256,256,512), 3 resnets per block, on a reduced frame (96x240, 9 frames):
+    every production kernel configuration (256-, 128- and 32-wide GEMM tiles, K up to 13 824)."""
+    from aether_amd.vae import AetherVAE
+    kw = dict(sample_height=96, sample_width=240)
+    cfg, sd, o32, o16 = _oracle_pair(kw, seed=2)
+    z = torch.randn(1, 16, 3, 12, 30, generator=torch.Generator().manual_seed(8)).to(torch.bfloat16)
+    ref = o32.decode(z.float()).sample
+    ref16 = o16.decode(z).sample
+    vae = AetherVAE(kw, device=cuda).load_state_dict(sd)
+    vae.enable_tiling()
+    got = vae.decode(z.to(cuda)).sample
+    torch.cuda.synchronize()
+    e_n, e_16 = _rel(got.cpu(), ref), _rel(ref16, ref)
+    print(f"full-width decode: native {e_n:.3e}  bf16-oracle {e_16:.3e}")
+    assert e_n < 1.5 * e_16 + 3e-3
+    x = _smooth_video(9, 96, 240, seed=2)
+    ref = o32.encode(x.float()).latent_dist.parameters
+    ref16 = o16.encode(x).latent_dist.parameters
+    got = vae.encode(x.to(cuda)).latent_dist.parameters
+    e_n, e_16 = _rel(got.cpu(), ref), _rel(ref16, ref)
+    print(f"full-width encode: native {e_n:.3e}  bf16-oracle {e_16:.3e}")
+    assert e_n < 1.5 * e_16 + 3e-3
+    _ = C

@@ -196,6 +196,82 @@ class AetherVAE:
         self._loaded = True
         return self
 
+    def state_dict_spec(self) -> Dict[str, tuple]:
+        """diffusers state-dict keys and shapes of an AutoencoderKLCogVideoX with this config."""
+        c = self.config
+        ch, z, nl = c.block_out_channels, c.latent_channels, c.layers_per_block
+        spec: Dict[str, tuple] = {}
+
+        def conv3(name, cin, cout, k=3):
+            spec[name + ".conv.weight"] = (cout, cin, k, k, k)
+            spec[name + ".conv.bias"] = (cout,)
+
+        def resnet(prefix, cin, cout, spatial):
+            for n, cc in (("norm1", cin), ("norm2", cout)):
+                if spatial:
+                    spec[f"{prefix}.{n}.norm_layer.weight"] = (cc,)
+                    spec[f"{prefix}.{n}.norm_layer.bias"] = (cc,)
+                    conv3(f"{prefix}.{n}.conv_y", z, cc, 1)
+                    conv3(f"{prefix}.{n}.conv_b", z, cc, 1)
+                else:
+                    spec[f"{prefix}.{n}.weight"] = (cc,)
+                    spec[f"{prefix}.{n}.bias"] = (cc,)
+            conv3(prefix + ".conv1", cin, cout)
+            conv3(prefix + ".conv2", cout, cout)
+            if cin != cout:
+                spec[prefix + ".conv_shortcut.weight"] = (cout, cin, 1, 1, 1)
+                spec[prefix + ".conv_shortcut.bias"] = (cout,)
+
+        conv3("encoder.conv_in", c.in_channels, ch[0])
+        cout = ch[0]
+        for i in range(len(ch)):
+            cin, cout = cout, ch[i]
+            for j in range(nl):
+                resnet(f"encoder.down_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout, False)
+            if i != len(ch) - 1:
+                spec[f"encoder.down_blocks.{i}.downsamplers.0.conv.weight"] = (cout, cout, 3, 3)
+                spec[f"encoder.down_blocks.{i}.downsamplers.0.conv.bias"] = (cout,)
+        for j in range(2):
+            resnet(f"encoder.mid_block.resnets.{j}", ch[-1], ch[-1], False)
+        spec["encoder.norm_out.weight"] = (ch[-1],)
+        spec["encoder.norm_out.bias"] = (ch[-1],)
+        conv3("encoder.conv_out", ch[-1], 2 * z)
+        rch = list(reversed(ch))
+        conv3("decoder.conv_in", z, rch[0])
+        for j in range(2):
+            resnet(f"decoder.mid_block.resnets.{j}", rch[0], rch[0], True)
+        cout = rch[0]
+        for i in range(len(rch)):
+            cin, cout = cout, rch[i]
+            for j in range(nl + 1):
+                resnet(f"decoder.up_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout, True)
+            if i != len(rch) - 1:
+                spec[f"decoder.up_blocks.{i}.upsamplers.0.conv.weight"] = (cout, cout, 3, 3)
+                spec[f"decoder.up_blocks.{i}.upsamplers.0.conv.bias"] = (cout,)
+        spec["decoder.norm_out.norm_layer.weight"] = (rch[-1],)
+        spec["decoder.norm_out.norm_layer.bias"] = (rch[-1],)
+        conv3("decoder.norm_out.conv_y", z, rch[-1], 1)
+        conv3("decoder.norm_out.conv_b", z, rch[-1], 1)
+        conv3("decoder.conv_out", rch[-1], c.out_channels)
+        return spec
+
+    def init_random_weights(self, seed: int = 0):
+        """Seeded synthetic weights (benchmarks; the real CogVideoX VAE checkpoint is not available offline):
+        fan-in-scaled convolutions so activations stay O(1) through the ~40 layers, norm weights 1 +- 0.1."""
+        g = torch.Generator().manual_seed(seed)
+        sd = {}
+        for k, shape in self.state_dict_spec().items():
+            if len(shape) >= 3:
+                fan_in = 1
+                for s in shape[1:]:
+                    fan_in *= s
+                sd[k] = torch.randn(shape, generator=g) * fan_in ** -0.5
+            elif k.endswith("weight"):
+                sd[k] = 1.0 + 0.1 * torch.randn(shape, generator=g)
+            else:
+                sd[k] = 0.02 * torch.randn(shape, generator=g)
+        return self.load_state_dict(sd)
+
     # ------------------------------------------------------------------------------------------------
     # low-level helpers (each enqueues exactly one HIP entry point)
     # ------------------------------------------------------------------------------------------------

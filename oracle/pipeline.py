@@ -14,8 +14,11 @@ from einops import rearrange
 @torch.no_grad()
 def sample(task, transformer, vae, scheduler, prompt_embeds, *, image=None, goal=None, video=None, raymap=None, height, width,
            num_frames, num_inference_steps=None, guidance_scale=None, use_dynamic_cfg=False, generator=None, fps=12,
-           rope=None, dtype=torch.bfloat16, device="cpu"):
-    """image/goal: [1,3,H,W] in [-1,1]; video: [F,3,H,W]; raymap: [1,F,6,h,w]. Returns (rgb, disparity, raymap) tensors."""
+           rope=None, dtype=torch.bfloat16, device="cpu", compute_dtype=None):
+    """image/goal: [1,3,H,W] in [-1,1]; video: [F,3,H,W]; raymap: [1,F,6,h,w]. Returns (rgb, disparity, raymap) tensors.
+    compute_dtype (calibration only): run the three modules in this dtype (e.g. fp32 weights) while every random draw
+    and every inter-module tensor keeps the reference dtype `dtype`, so runs at different precision see the SAME noise."""
+    cd = compute_dtype or dtype
     defaults_steps = {"reconstruction": 4, "prediction": 50, "planning": 50}                        # P:257-261
     defaults_g = {"reconstruction": 1.0, "prediction": 3.0, "planning": 3.0}                        # P:262-266
     defaults_dyn = {"reconstruction": False, "prediction": True, "planning": True}                  # P:267-271
@@ -30,7 +33,11 @@ def sample(task, transformer, vae, scheduler, prompt_embeds, *, image=None, goal
     shape = (1, lat_frames, 56, height // 8, width // 8)                                              # P:536-542
 
     def enc(x):                                                                                       # P:557-576
-        z = vae.encode(x).latent_dist.sample(generator)
+        dist = vae.encode(x.to(cd)).latent_dist
+        if cd == dtype:
+            z = dist.sample(generator)
+        else:   # same bf16 noise as the reference-dtype run, higher-precision mean/std
+            z = dist.mean + dist.std * torch.randn(dist.mean.shape, generator=generator, dtype=dtype).to(cd)
         return sf * z.to(dtype).permute(0, 2, 1, 3, 4)
 
     if image is not None:
@@ -73,7 +80,7 @@ def sample(task, transformer, vae, scheduler, prompt_embeds, *, image=None, goal
         else:
             c_in = cond
         lat_in = torch.cat([lat_in, c_in], dim=2)                                                     # P:857-859
-        pred = transformer(hidden_states=lat_in, encoder_hidden_states=prompt_embeds.repeat(lat_in.shape[0], 1, 1),
+        pred = transformer(hidden_states=lat_in.to(cd), encoder_hidden_states=prompt_embeds.repeat(lat_in.shape[0], 1, 1).to(cd),
                            timestep=t.expand(lat_in.shape[0]), ofs=None, image_rotary_emb=rope, return_dict=False)[0].float()
         if use_dynamic_cfg:                                                                           # P:879-893
             g_now = 1 + guidance_scale * ((1 - math.cos(math.pi * ((num_inference_steps - t.item()) / num_inference_steps) ** 5.0)) / 2)
@@ -85,7 +92,7 @@ def sample(task, transformer, vae, scheduler, prompt_embeds, *, image=None, goal
         latents = latents.to(dtype)                                                                   # P:916
 
     def dec(z):                                                                                       # decode_latents
-        return vae.decode(1 / sf * z.permute(0, 2, 1, 3, 4)).sample
+        return vae.decode((1 / sf * z.permute(0, 2, 1, 3, 4)).to(cd)).sample.to(dtype)
 
     rgb = dec(latents[:, :, :16])                                                                     # P:925-934
     rgb = (rgb[0].permute(1, 0, 2, 3) / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).float()

@@ -147,3 +147,13 @@ def test_raymap_packing_is_outer_factor():
     assert packed[0, 3, :6, 0, 0].tolist() == r[0, 3, :, 0, 0].tolist()
     assert packed[0, 3, 6:12, 0, 0].tolist() == r[0, 14, :, 0, 0].tolist()
     assert torch.equal(rearrange(packed, "b t (n c) h w -> b (n t) c h w", n=4), r)
+
+
+def test_vae_state_dict_spec_matches_oracle_keys():
+    """The native VAE's notion of the diffusers key layout equals the oracle module's state dict."""
+    from aether_amd.vae import AetherVAE
+    from oracle.vae import OracleVAE, VaeConfig
+    for kw in (dict(), dict(block_out_channels=(64, 128, 128, 128), layers_per_block=1)):
+        spec = AetherVAE(kw, device="cpu").state_dict_spec()
+        ref = {k: tuple(v.shape) for k, v in OracleVAE(VaeConfig(**kw)).state_dict().items()}
+        assert spec == ref

@@ -44,9 +44,9 @@ SIGNATURES = {
     "aether_flash_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "aether_conv_gemm_bf16": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _fp, _vp, _i, _i, _vp]),
     "aether_im2col_first": (_i, [_vp, C.c_long, C.c_long, C.c_long, C.c_long, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
-    "aether_groupnorm_stats": (_i, [_vp, _i, _i, _i, _i, _f, _fp, _i, _fp, _vp]),
-    "aether_groupnorm_apply": (_i, [_vp, _i, _i, _i, _i, _i, _i, _fp, _fp, _fp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i,
-                                    _fp, _fp, _fp, _fp, C.POINTER(C.c_int), _vp]),
+    "aether_groupnorm_stats": (_i, [_vp, _i, _i, _i, _i, _f, _fp, _fp, _fp, _i, _fp, _fp, _vp]),
+    "aether_spatial_cond": (_i, [_vp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _vp]),
+    "aether_groupnorm_apply": (_i, [_vp, _i, _i, _i, _i, _i, _fp, _i, _vp, _i, _i, _i, _i, _i, _i, _fp, _i, _i, _i, C.POINTER(C.c_int), _vp]),
     "aether_resample_pad": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "aether_dit_create": (_vp, [C.POINTER(AetherDitConfig)]),
     "aether_dit_destroy": (None, [_vp]),

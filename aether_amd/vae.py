@@ -324,25 +324,28 @@ class AetherVAE:
         NB, T, H, W, Cc = x.shape
         G = self.config.norm_num_groups
         V = T * H * W
-        nblk = max(1, min(1024, (V + 255) // 256))
+        nblk = max(1, min(512, (V + 127) // 128))
         part = torch.empty(NB * nblk * 2 * Cc, dtype=torch.float32, device=self.device)
         stats = torch.empty(NB * G * 2, dtype=torch.float32, device=self.device)
+        affine = torch.empty(NB * 2 * Cc, dtype=torch.float32, device=self.device)
         eps = 1e-6 if (eps is None or norm.spatial) else eps
-        _lib.check(self._lib.aether_groupnorm_stats(x.data_ptr(), NB, V, Cc, G, float(eps), part.data_ptr(), nblk, stats.data_ptr(),
-                                                    self._stream()), "aether_groupnorm_stats")
+        _lib.check(self._lib.aether_groupnorm_stats(x.data_ptr(), NB, V, Cc, G, float(eps), norm.gamma.data_ptr(), norm.beta.data_ptr(),
+                                                    part.data_ptr(), nblk, stats.data_ptr(), affine.data_ptr(), self._stream()),
+                   "aether_groupnorm_stats")
         vol = self._padded((NB, T + pad_t, H + 2 * pad_hw, W + 2 * pad_hw, Cc))
         if norm.spatial:
-            zT = zq.shape[1]
+            _, zT, zH, zW, zC = zq.shape
+            cond = torch.empty(NB * zT * zH * zW * 2 * Cc, dtype=torch.float32, device=self.device)
+            _lib.check(self._lib.aether_spatial_cond(zq.data_ptr(), NB, zT * zH * zW, zC, Cc, norm.wy.data_ptr(), norm.by.data_ptr(),
+                                                     norm.wb.data_ptr(), norm.bb.data_ptr(), cond.data_ptr(), self._stream()),
+                       "aether_spatial_cond")
             tmap = (C.c_int * T)(*_nearest_time_map(T, zT))
-            rc = self._lib.aether_groupnorm_apply(x.data_ptr(), NB, T, H, W, Cc, G, stats.data_ptr(), norm.gamma.data_ptr(),
-                                                  norm.beta.data_ptr(), int(silu), vol.data_ptr(), vol.shape[1], vol.shape[2], vol.shape[3],
-                                                  pad_t, pad_hw, pad_hw, zq.data_ptr(), zT, zq.shape[2], zq.shape[3], zq.shape[4],
-                                                  norm.wy.data_ptr(), norm.by.data_ptr(), norm.wb.data_ptr(), norm.bb.data_ptr(), tmap,
+            rc = self._lib.aether_groupnorm_apply(x.data_ptr(), NB, T, H, W, Cc, affine.data_ptr(), int(silu), vol.data_ptr(), vol.shape[1],
+                                                  vol.shape[2], vol.shape[3], pad_t, pad_hw, pad_hw, cond.data_ptr(), zT, zH, zW, tmap,
                                                   self._stream())
         else:
-            rc = self._lib.aether_groupnorm_apply(x.data_ptr(), NB, T, H, W, Cc, G, stats.data_ptr(), norm.gamma.data_ptr(),
-                                                  norm.beta.data_ptr(), int(silu), vol.data_ptr(), vol.shape[1], vol.shape[2], vol.shape[3],
-                                                  pad_t, pad_hw, pad_hw, None, 0, 0, 0, 0, None, None, None, None, None, self._stream())
+            rc = self._lib.aether_groupnorm_apply(x.data_ptr(), NB, T, H, W, Cc, affine.data_ptr(), int(silu), vol.data_ptr(), vol.shape[1],
+                                                  vol.shape[2], vol.shape[3], pad_t, pad_hw, pad_hw, None, 0, 0, 0, None, self._stream())
         _lib.check(rc, "aether_groupnorm_apply")
         return vol
 

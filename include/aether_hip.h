@@ -125,19 +125,25 @@ int aether_conv_gemm_bf16(const void* X, int NB, int iT, int iH, int iW, int iC,
 int aether_im2col_first(const void* x, long sC, long sT, long sH, long sW, int Cin, int t0, int first_chunk, int y0, int x0,
                         int T, int H, int W, void* A, int Kpad, void* stream);
 
-/* GroupNorm statistics of x [NB, V, C] -> stats fp32 [NB, G, 2] = (mean, rstd).  Deterministic: per-block
+/* GroupNorm statistics of x [NB, V, C] -> stats fp32 [NB, G, 2] = (mean, rstd) and the folded per-channel affine
+ * table affine fp32 [NB, 2, C] (scale = rstd*gamma, shift = beta - mean*rstd*gamma).  Deterministic: per-block
  * per-channel partial sums (partial_ws fp32 [NB, nblk, 2, C]) merged in double with the parallel-variance formula. */
-int aether_groupnorm_stats(const void* x, int NB, int V, int C, int G, float eps, float* partial_ws, int nblk, float* stats,
-                           void* stream);
+int aether_groupnorm_stats(const void* x, int NB, int V, int C, int G, float eps, const float* gamma, const float* beta,
+                           float* partial_ws, int nblk, float* stats, float* affine, void* stream);
 
-/* y = [silu]( GN(x)·gamma+beta  [· (Wy·zq+by) + (Wb·zq+bb)] ) written at interior offset (pt,ph,pw) of the
- * zero-bordered volume y [NB, oT, oH, oW, C].  zq != NULL selects CogVideoXSpatialNorm3D: zq is the latent
- * [NB, zT, zH, zW, zC<=16] channels-last, nearest-resized (tmap_host[t] = source latent frame of frame t, host
- * array of T ints; H % zH == 0, W % zW == 0); wy,wb fp32 [C, zC]; by,bb fp32 [C]. */
-int aether_groupnorm_apply(const void* x, int NB, int T, int H, int W, int C, int G, const float* stats, const float* gamma,
-                           const float* beta, int silu_flag, void* y, int oT, int oH, int oW, int pt, int ph, int pw,
-                           const void* zq, int zT, int zH, int zW, int zC, const float* wy, const float* by, const float* wb,
-                           const float* bb, const int* tmap_host, void* stream);
+/* CogVideoXSpatialNorm3D conditioning at LATENT resolution (nearest up-sampling commutes with a 1x1x1 conv):
+ * cond fp32 [NB, zV, 2, C]: [.,.,0,:] = conv_y(zq), [.,.,1,:] = conv_b(zq); zq bf16 [NB, zV, zC] channels-last;
+ * wy,wb fp32 [C, zC]; by,bb fp32 [C]. */
+int aether_spatial_cond(const void* zq, int NB, int zV, int zC, int C, const float* wy, const float* by, const float* wb,
+                        const float* bb, float* cond, void* stream);
+
+/* y = [silu]( (x*scale+shift) [* cond_y + cond_b] ) written at interior offset (pt,ph,pw) of the zero-bordered
+ * volume y [NB, oT, oH, oW, C].  cond != NULL selects SpatialNorm3D: cond fp32 [NB, zT, zH, zW, 2, C] from
+ * aether_spatial_cond, gathered at the nearest latent voxel (tmap_host[t] = source latent frame of frame t, host
+ * array of T <= 16 ints; H % zH == 0; W / zW a power of two).  C/8 must be a power of two. */
+int aether_groupnorm_apply(const void* x, int NB, int T, int H, int W, int C, const float* affine, int silu_flag, void* y,
+                           int oT, int oH, int oW, int pt, int ph, int pw, const float* cond, int zT, int zH, int zW,
+                           const int* tmap_host, void* stream);
 
 /* Resample x [NB,T,H,W,C] into a zero-bordered volume y [NB,oT,oH,oW,C] at interior offset (pt,ph,pw).
  * mode 0 copy; 1 temporal avg-pool k2 s2 (first frame kept when T is odd; CogVideoXDownsample3D);

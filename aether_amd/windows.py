@@ -1,0 +1,115 @@
+"""Sliding-window driver for long-video reconstruction and its multi-GPU sharding.
+
+Reference behaviour (/root/reference/scripts/demo.py:235-251, 607-631): a video longer than `num_frames` is cut into
+41-frame windows starting every `sliding_window_stride` frames (plus one tail window flush with the end); every window
+is a full, independent pipeline call with a FRESH generator seeded with the same seed (D:629); the windows are then
+blended on the CPU, sequentially (D:254-422).  The reference runs the windows one after the other on one GPU.
+
+Here windows are independent units: with one process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI on
+MI355X, "gloo" in the CPU tests) window w runs on rank w mod N, weights are replicated and nothing is exchanged during
+denoising.  The only collective is ONE all_gather of the finished per-window outputs (rgb 170 MB + disparity 57 MB +
+raymap 5 MB fp32 per window) so that rank 0 can run the sequential blend exactly as the reference does.  Results are
+bit-identical to the single-process run for any N (same seeds, same per-window arithmetic, gather only moves data).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+
+def get_window_starts(total_frames: int, sliding_window_size: int, temporal_stride: int) -> List[int]:
+    """D:235-251: regular starts every `temporal_stride`, plus a last window flush with the end of the video."""
+    last = total_frames - sliding_window_size
+    starts = list(range(0, last + 1, temporal_stride))
+    if total_frames > sliding_window_size and last % temporal_stride != 0:
+        starts.append(last)
+    return starts
+
+
+@dataclass
+class WindowResult:
+    start: int
+    rgb: np.ndarray         # [F, H, W, 3] float32
+    disparity: np.ndarray   # [F, H, W]    float32
+    raymap: np.ndarray      # [F, 6, h, w] float32
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if (dist.is_available() and dist.is_initialized()) else None
+
+
+def shard(items: Sequence, rank: int, world: int) -> List:
+    """Round-robin assignment: item i -> rank i mod world (8 windows on 8/4/2/1 GPUs = 1/2/4/8 windows per rank)."""
+    return [x for i, x in enumerate(items) if i % world == rank]
+
+
+def run_windows(call_window: Callable[[int], "object"], starts: Sequence[int], gather_device: Optional[torch.device] = None
+                ) -> Optional[List[WindowResult]]:
+    """Runs `call_window(start)` (one pipeline call returning .rgb/.disparity/.raymap numpy arrays) for this rank's share of
+    `starts`, then all_gathers the outputs.  Returns the complete, start-ordered list on rank 0 (None on other ranks).
+    Without an initialised process group it simply runs every window in order."""
+    dist = _dist()
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
+    mine = shard(list(enumerate(starts)), rank, world)
+    local = []
+    for idx, s in mine:
+        out = call_window(s)
+        local.append((idx, WindowResult(s, np.asarray(out.rgb, np.float32), np.asarray(out.disparity, np.float32),
+                                        np.asarray(out.raymap, np.float32))))
+    if dist is None or world == 1:
+        return [r for _, r in local]
+
+    # ---- one all_gather: every rank contributes ceil(n/world) slots (unused slots zero, index -1) -----------------
+    per_rank = (len(starts) + world - 1) // world
+    shapes = None
+    if local:
+        r0 = local[0][1]
+        shapes = (r0.rgb.shape, r0.disparity.shape, r0.raymap.shape)
+    all_shapes = [None] * world
+    dist.all_gather_object(all_shapes, shapes)
+    shapes = next(s for s in all_shapes if s is not None)
+    sizes = [int(np.prod(s)) for s in shapes]
+    dev = gather_device if (gather_device is not None and dist.get_backend() == "nccl") else torch.device("cpu")
+    payload = torch.zeros(per_rank, sum(sizes), dtype=torch.float32, device=dev)
+    index = torch.full((per_rank,), -1, dtype=torch.int64, device=dev)
+    for slot, (idx, r) in enumerate(local):
+        flat = np.concatenate([r.rgb.ravel(), r.disparity.ravel(), r.raymap.ravel()])
+        payload[slot].copy_(torch.from_numpy(flat))
+        index[slot] = idx
+    gathered = [torch.empty_like(payload) for _ in range(world)]
+    gathered_idx = [torch.empty_like(index) for _ in range(world)]
+    dist.all_gather(gathered, payload)
+    dist.all_gather(gathered_idx, index)
+    if rank != 0:
+        return None
+    results: List[Optional[WindowResult]] = [None] * len(starts)
+    for g, gi in zip(gathered, gathered_idx):
+        g, gi = g.cpu().numpy(), gi.cpu().tolist()
+        for slot, idx in enumerate(gi):
+            if idx < 0:
+                continue
+            a, b, c = np.split(g[slot], np.cumsum(sizes)[:-1])
+            results[idx] = WindowResult(starts[idx], a.reshape(shapes[0]).copy(), b.reshape(shapes[1]).copy(), c.reshape(shapes[2]).copy())
+    assert all(r is not None for r in results)
+    return results
+
+
+def blend_rgb(results: Sequence[WindowResult], total_frames: int) -> np.ndarray:
+    """Linear cross-fade of the RGB frames of overlapping windows (the colour part of D:254-422; the geometric part —
+    disparity scale fitting, pose alignment — stays with the reference's numpy post-processing)."""
+    f, h, w, c = results[0].rgb.shape
+    out = np.zeros((total_frames, h, w, c), np.float32)
+    filled = 0
+    for r in results:
+        s = r.start
+        overlap = max(filled - s, 0)
+        if overlap > 0:
+            wgt = np.linspace(0.0, 1.0, overlap, dtype=np.float32)[:, None, None, None]
+            out[s:s + overlap] = out[s:s + overlap] * (1 - wgt) + r.rgb[:overlap] * wgt
+        out[s + overlap:s + f] = r.rgb[overlap:]
+        filled = max(filled, s + f)
+    return out

@@ -67,6 +67,41 @@ def cpu_baseline(cfg_overrides, S_video_shape, seconds_budget=30.0):
                       f"oracle, {dt:.1f} s), extrapolated x{cfg.num_layers}; host has {os.cpu_count()} logical cores"}
 
 
+def clip_wall_clock(transformer, dev, steps):
+    """Wall-clock of ONE whole pipeline call (BASELINE metric, second half): reconstruction of a synthetic 41x480x720 clip
+    through the drop-in entry point — VAE encode (tiled, 9 tiles x 5 frame chunks), `steps` denoise steps, two VAE decodes,
+    D2H of rgb/disparity/raymap — random-init weights, device generator seeded like scripts/demo.py:629."""
+    import numpy as np
+
+    from aether.pipelines.aetherv1_pipeline_cogvideox import AetherV1PipelineCogVideoX
+    from aether_amd.scheduler import CogVideoXDPMScheduler
+    from aether_amd.vae import AetherVAE
+
+    vae = AetherVAE(device=dev).init_random_weights(1)
+    vae.enable_slicing()
+    vae.enable_tiling()
+    g = torch.Generator().manual_seed(0)
+    prompt = (torch.randn(1, 226, 4096, generator=g) * 0.1).to(torch.bfloat16)
+    pipe = AetherV1PipelineCogVideoX(tokenizer=None, text_encoder=None, vae=vae, scheduler=CogVideoXDPMScheduler(),
+                                     transformer=transformer, empty_prompt_embeds=prompt)
+    pipe.set_progress_bar_config(disable=True)
+    yy, xx = np.mgrid[0:480, 0:720].astype(np.float32)
+    video = np.stack([np.stack([0.5 + 0.4 * np.sin(0.02 * xx + 0.1 * t + c) * np.cos(0.015 * yy) for c in range(3)], -1)
+                      for t in range(41)]).astype(np.float32)
+    out = {}
+    for label, n in (("warmup", 1), (f"reconstruction_{steps}_steps", steps), ("reconstruction_4_steps_reference_default", 4)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = pipe(task="reconstruction", video=video, height=480, width=720, num_frames=41, num_inference_steps=n, fps=12,
+                   generator=torch.Generator(device=dev).manual_seed(42))
+        torch.cuda.synchronize()
+        if label != "warmup":
+            out[label] = {"seconds": time.perf_counter() - t0, "steps": n}
+        assert res.rgb.shape == (41, 480, 720, 3) and np.isfinite(res.rgb).all() and np.isfinite(res.disparity).all()
+    out["unit"] = "s per 41f 480x720 clip (VAE encode + steps + 2 decodes + D2H), 1 GPU"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,6 +109,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--layers", type=int, default=42, help="debug only; anything but 42 marks the line invalid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-clip", action="store_true", help="skip the end-to-end clip wall-clock leg (pipeline incl. VAE)")
+    ap.add_argument("--clip-steps", type=int, default=50, help="sampler steps of the clip leg (reference default for reconstruction: 4)")
     ap.add_argument("--cfg", action="store_true", help="B=2 (prediction/planning CFG) instead of reconstruction B=1")
     args = ap.parse_args()
 
@@ -180,6 +217,8 @@ def main():
                               if flops_per_launch(k, B, S, D, FF) > 0 and ms > 0},
             "gpu_kernel_ms_per_step_total": total_ms / args.steps,
         }
+        if world == 1 and not args.no_clip:
+            line["clip"] = clip_wall_clock(model, dev, args.clip_steps)
         if world == 1 and not args.no_cpu_baseline:
             del model
             torch.cuda.empty_cache()

@@ -49,6 +49,7 @@ extern "C" int aether_gemm_bf16(const void* A, int lda, const void* W, int ldw, 
     p.n_text = n_text;
     p.tiles_m = (M + 255) / 256;
     p.tiles_n = (N + 255) / 256;
+    p.stagger = (flags >> 2) & 3;
     dim3 grid(p.tiles_m * p.tiles_n), block(512);
     hipStream_t s = (hipStream_t)stream;
     const bool wide = (flags & AETHER_GEMM_WIDE_STORE) != 0;

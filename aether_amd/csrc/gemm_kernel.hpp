@@ -39,6 +39,8 @@ struct GemmArgs {
     int oT, oH, oW;             // output volume per batch item: M = NB*oT*oH*oW, row m = ((nb*oT+t)*oH+h)*oW+w
     int iT, iH, iW, iC;         // padded input volume dims (frames, rows, cols, channels per voxel)
     int stride_hw;              // spatial stride (1, or 2 for the down-sampling conv2d)
+    int stagger;                // LDS-DMA issue placement: 0 = all at the top of the K tile; 1 = waves 4-7 (the second wave
+                                // of every SIMD) issue theirs after the second k-step; 2 = one quarter before every k-step
 };
 
 constexpr int GEMM_BK = 64;
@@ -110,6 +112,21 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
             for (int r = 0; r < W_ROUNDS; ++r) glds16(Wk + w_off[r], dst + A_TILE + r * 8192);
         }
     };
+    // quarter q (0..3) of the same tile: used to spread the DMA issue cost over the four k-steps
+    auto stage_quarter = [&](int kt, int buf, int q) {
+        const bf16_t* Ak = p.A + (GATHER ? p.tap_off[kt] : kt * GEMM_BK);
+        const bf16_t* Wk = p.W + kt * GEMM_BK;
+        char* dst = lds_stage + buf * BUF_BYTES;
+#pragma unroll
+        for (int r = 0; r < A_ROUNDS; ++r)
+            if (r * 4 / A_ROUNDS == q) glds16(Ak + a_off[r], dst + r * 8192);
+        if (w_active) {
+#pragma unroll
+            for (int r = 0; r < W_ROUNDS; ++r)
+                if ((W_ROUNDS >= 4 ? r * 4 / W_ROUNDS : r) == q) glds16(Wk + w_off[r], dst + A_TILE + r * 8192);
+        }
+    };
+    const int late_wave = __builtin_amdgcn_readfirstlane(wave >> 2);   // waves 4-7 share SIMDs with waves 0-3
 
     // ---- fragment read addresses -----------------------------------------------------------------------------------
     const int swz = (lane >> 1) & 7;
@@ -133,10 +150,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+        const bool has_next = kt + 1 < nk;
+        if (has_next && (p.stagger == 0 || (p.stagger == 1 && late_wave == 0))) stage(kt + 1, cur ^ 1);
         const char* base = smem + cur * BUF_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
+            if (ks == 2 && has_next && p.stagger == 1 && late_wave != 0) stage(kt + 1, cur ^ 1);
+            if (has_next && p.stagger == 2) stage_quarter(kt + 1, cur ^ 1, ks);
             bf16x8 wf[NT], xf[MT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) wf[nt] = *(const bf16x8*)(base + w_row_base + nt * 4096 + chunk_off[ks]);

@@ -149,6 +149,7 @@ extern "C" int aether_conv_gemm_bf16(const void* X, int NB, int iT, int iH, int 
     p.tap_off = tap_off;
     p.oT = oT; p.oH = oH; p.oW = oW; p.iT = iT; p.iH = iH; p.iW = iW; p.iC = iC; p.stride_hw = stride_hw;
     const bool wide = (flags & AETHER_GEMM_WIDE_STORE) != 0;
+    p.stagger = (flags >> 2) & 3;
     dim3 block(512);
 #define LAUNCH_CFG(WM_, WN_, MT_, NT_, BM_, BN_)                                                                                   \
     do {                                                                                                                            \

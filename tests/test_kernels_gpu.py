@@ -28,7 +28,7 @@ def _bf16_close(got, ref_fp32, what, rel=6e-3, max_ulp_frac=2.0):
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 256), (300, 256, 128), (1000, 512, 3072), (226, 512, 4096), (37, 224, 512)])
-@pytest.mark.parametrize("flags", [0, 1])
+@pytest.mark.parametrize("flags", [0, 1, 1 | (1 << 2), 1 | (2 << 2)])     # bits 2-3: LDS-DMA issue placement variants
 def test_gemm_bias(cuda, hip_lib, M, N, K, flags):
     from aether_amd import ops
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
@@ -229,6 +229,7 @@ def test_flash_attention_online_max_jump(cuda, hip_lib):
     qb, kb, vb = [t.to(torch.bfloat16) for t in (q * 0.125, k, v)]
     ref = torch.nn.functional.scaled_dot_product_attention(qb.float(), kb.float(), vb.float(), scale=1.0)
     vt = vb.transpose(2, 3).contiguous()
-    out = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda))
-    torch.cuda.synchronize()
-    _bf16_close(out, ref.transpose(1, 2).reshape(B, S, 64), "flash max-jump", rel=1.5e-2, max_ulp_frac=4.0)
+    for flags in (0, 1):
+        out = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags)
+        torch.cuda.synchronize()
+        _bf16_close(out, ref.transpose(1, 2).reshape(B, S, 64), f"flash max-jump flags={flags}", rel=1.5e-2, max_ulp_frac=4.0)

@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--out", default="gpurun_out/microbench.json")
     ap.add_argument("--S", type=int, default=15076)
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--only", default="", help="comma list of sections: gemm,attn,stream")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(0)
@@ -46,20 +47,21 @@ def main():
     def rnd(*shape, scale=1.0, dtype=torch.bfloat16):
         return (torch.randn(*shape, generator=g, device=dev, dtype=torch.float32) * scale).to(dtype)
 
+    only = set(x for x in args.only.split(",") if x)
     # ---- GEMMs -------------------------------------------------------------------------------
-    for name, (M, N, K, epi) in {
+    for name, (M, N, K, epi) in ({} if (only and "gemm" not in only) else {
         "gemm_qkv": (S, 3 * D, D, ops.AETHER_EPI_BIAS),
         "gemm_out": (S, D, D, ops.AETHER_EPI_BIAS_GATE_RES),
         "gemm_ff1": (S, FF, D, ops.AETHER_EPI_BIAS_GELU),
         "gemm_ff2": (S, D, FF, ops.AETHER_EPI_BIAS_GATE_RES),
         "gemm_4096_cube": (4096, 4096, 4096, ops.AETHER_EPI_BIAS),
         "gemm_8192_cube": (8192, 8192, 8192, ops.AETHER_EPI_BIAS),
-    }.items():
+    }).items():
         A, W, bias = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(N, dtype=torch.float32)
         out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
         R = rnd(M, N) if epi == ops.AETHER_EPI_BIAS_GATE_RES else None
         gate = rnd(1, 2 * N, dtype=torch.float32) if R is not None else None
-        for flags in (0, 1):
+        for flags in (1, 1 | (1 << 2)):
             kw = dict(R=R, gate_vid=gate[:, :N], gate_txt=gate[:, N:], rows_per_batch=M, n_text=226) if R is not None else {}
             t = timeit(lambda: ops.gemm_bf16(A, W, bias, epi, out=out, flags=flags, **kw))
             tf = 2.0 * M * N * K / t / 1e12
@@ -69,7 +71,7 @@ def main():
         del A, W, out, R
 
     # ---- attention ---------------------------------------------------------------------------
-    for B in ((1,) if args.quick else (1, 2)):
+    for B in (() if (only and "attn" not in only) else ((1,) if args.quick else (1, 2))):
         q, k = rnd(B, H, S, 64, scale=0.125 * 1.0), rnd(B, H, S, 64)
         Spad = (S + 63) // 64 * 64
         vt = rnd(B, H, 64, Spad)
@@ -83,6 +85,10 @@ def main():
         del q, k, vt
 
     # ---- streaming kernels -------------------------------------------------------------------
+    if only and "stream" not in only:
+        os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
+        json.dump(res, open(args.out, "w"), indent=1)
+        return
     x = rnd(S, D)
     w, b = rnd(D, dtype=torch.float32), rnd(D, dtype=torch.float32)
     mod = rnd(1, 6 * D, dtype=torch.float32)

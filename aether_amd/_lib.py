@@ -15,7 +15,8 @@ AETHER_EPI_BIAS = 0
 AETHER_EPI_BIAS_GELU = 1
 AETHER_EPI_BIAS_GATE_RES = 2
 AETHER_GEMM_WIDE_STORE = 1
-AETHER_GEMM_STAGGER_LATE = 1 << 2   # AETHER_GEMM_STAGGER(1): waves 4-7 issue their LDS-DMA mid K-tile (+2..4 %)
+AETHER_GEMM_PINGPONG = 4      # ping-pong main loop (see include/aether_hip.h)
+AETHER_GEMM_PINGPONG2 = 8
 PROF_CLASSES = ["other", "layernorm", "gemm_qkv", "qk_norm_rope", "attention", "gemm_out", "gemm_ff1", "gemm_ff2"]
 
 _vp, _i, _f, _fp, _sz = C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_size_t

@@ -15,6 +15,7 @@
 //   gathered: row m starts at A + voxel_offset(m) (a zero-padded channels-last activation volume) and K step kt
 //             adds tap_off[kt] elements — the (dt,dh,dw) tap and 64-channel block of an implicit-GEMM convolution.
 #pragma once
+#include <type_traits>
 #include "common.hpp"
 
 namespace aether {
@@ -39,8 +40,8 @@ struct GemmArgs {
     int oT, oH, oW;             // output volume per batch item: M = NB*oT*oH*oW, row m = ((nb*oT+t)*oH+h)*oW+w
     int iT, iH, iW, iC;         // padded input volume dims (frames, rows, cols, channels per voxel)
     int stride_hw;              // spatial stride (1, or 2 for the down-sampling conv2d)
-    int stagger;                // LDS-DMA issue placement: 0 = all at the top of the K tile; 1 = waves 4-7 (the second wave
-                                // of every SIMD) issue theirs after the second k-step; 2 = one quarter before every k-step
+    int stagger;                // main loop: 0 = one barrier per K tile (all waves in lock-step); 1 = ping-pong, one k-step per
+                                // slot; 2 = ping-pong, two k-steps per slot
 };
 
 constexpr int GEMM_BK = 64;
@@ -112,20 +113,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
             for (int r = 0; r < W_ROUNDS; ++r) glds16(Wk + w_off[r], dst + A_TILE + r * 8192);
         }
     };
-    // quarter q (0..3) of the same tile: used to spread the DMA issue cost over the four k-steps
-    auto stage_quarter = [&](int kt, int buf, int q) {
-        const bf16_t* Ak = p.A + (GATHER ? p.tap_off[kt] : kt * GEMM_BK);
-        const bf16_t* Wk = p.W + kt * GEMM_BK;
-        char* dst = lds_stage + buf * BUF_BYTES;
-#pragma unroll
-        for (int r = 0; r < A_ROUNDS; ++r)
-            if (r * 4 / A_ROUNDS == q) glds16(Ak + a_off[r], dst + r * 8192);
-        if (w_active) {
-#pragma unroll
-            for (int r = 0; r < W_ROUNDS; ++r)
-                if ((W_ROUNDS >= 4 ? r * 4 / W_ROUNDS : r) == q) glds16(Wk + w_off[r], dst + A_TILE + r * 8192);
-        }
-    };
     const int late_wave = __builtin_amdgcn_readfirstlane(wave >> 2);   // waves 4-7 share SIMDs with waves 0-3
 
     // ---- fragment read addresses -----------------------------------------------------------------------------------
@@ -148,15 +135,106 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
     stage(0, 0);
     drain_and_barrier();
 
+    if (p.stagger != 0) {
+        // ---- "ping-pong" main loop -------------------------------------------------------------------------------
+        // The two waves that share a SIMD (w and w+4) alternate roles every slot, phase-locked by s_barrier: while one
+        // issues its MFMAs for KSPS k-steps (fragments already in registers) the other reads its next fragments from
+        // LDS; the LDS-DMA pieces of the next K tile are issued in the shadow of the MFMAs.  With KSPS = 1 (8 slots / tile):
+        //   group 0 (waves 0-3):  L0 C0 L1 C1 L2 C2 L3 C3        group 1 (waves 4-7):  C3' L0 C0 L1 C1 L2 C2 L3
+        // (C3' = last compute slot of the previous tile); KSPS = 2 halves the number of slots (16 MFMAs per slot).
+        // The matrix pipe of every SIMD always has exactly one wave feeding it.
+        auto pingpong = [&](auto ksps_tag) {
+            constexpr int KSPS = decltype(ksps_tag)::value;
+            constexpr int NSLOT = 4 / KSPS;            // compute slots per K tile
+            bf16x8 wf[KSPS][NT], xf[KSPS][MT];
+            auto load_frags = [&](const char* base, int slot) {
+#pragma unroll
+                for (int k = 0; k < KSPS; ++k) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) wf[k][nt] = *(const bf16x8*)(base + w_row_base + nt * 4096 + chunk_off[slot * KSPS + k]);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) xf[k][mt] = *(const bf16x8*)(base + x_row_base + mt * 4096 + chunk_off[slot * KSPS + k]);
+                }
+            };
+            // DMA pieces of tile kt split in NPART parts, one per early compute slot
+            constexpr int NPART = (KSPS == 1) ? 3 : 1;
+            auto stage_part = [&](int kt, int buf, int part) {
+                const bf16_t* Ak = p.A + (GATHER ? p.tap_off[kt] : kt * GEMM_BK);
+                const bf16_t* Wk = p.W + kt * GEMM_BK;
+                char* dst = lds_stage + buf * BUF_BYTES;
+                constexpr int NP = A_ROUNDS + W_ROUNDS;
+#pragma unroll
+                for (int r = 0; r < A_ROUNDS; ++r)
+                    if (r * NPART / NP == part) glds16(Ak + a_off[r], dst + r * 8192);
+                if (w_active) {
+#pragma unroll
+                    for (int r = 0; r < W_ROUNDS; ++r)
+                        if ((A_ROUNDS + r) * NPART / NP == part) glds16(Wk + w_off[r], dst + A_TILE + r * 8192);
+                }
+            };
+            auto mma_with_stage = [&](bool do_stage, int kt, int part) {
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int k = 0; k < KSPS; ++k)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        if (k == 0 && mt == MT / 2 && do_stage) stage_part(kt, kt & 1, part);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[k][nt], xf[k][mt], acc[mt][nt], 0, 0, 0);
+                    }
+                __builtin_amdgcn_s_setprio(0);
+            };
+            auto slot_end = [&]() {
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            if (late_wave == 0) {
+                for (int kt = 0; kt < nk; ++kt) {
+                    const char* base = smem + (kt & 1) * BUF_BYTES;
+                    const bool has_next = kt + 1 < nk;
+#pragma unroll
+                    for (int sl = 0; sl < NSLOT; ++sl) {
+                        load_frags(base, sl);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        slot_end();
+                        mma_with_stage(has_next && sl < NPART, kt + 1, sl);
+                        if (sl == NSLOT - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        slot_end();
+                    }
+                }
+            } else {
+                for (int kt = 0; kt < nk; ++kt) {
+                    const char* base = smem + (kt & 1) * BUF_BYTES;
+                    const bool has_next = kt + 1 < nk;
+                    if (kt > 0) mma_with_stage(has_next, kt + 1, 0);   // last compute slot of the previous tile
+                    else if (has_next) stage_part(kt + 1, (kt + 1) & 1, 0);
+                    slot_end();
+#pragma unroll
+                    for (int sl = 0; sl < NSLOT; ++sl) {
+                        load_frags(base, sl);
+                        if (sl == NSLOT - 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        slot_end();
+                        if (sl < NSLOT - 1) {
+                            mma_with_stage(has_next && sl + 1 < NPART, kt + 1, sl + 1);
+                            slot_end();
+                        }
+                    }
+                }
+                mma_with_stage(false, 0, 0);                                   // last compute slot of the last tile
+            }
+        };
+        if (p.stagger == 1) pingpong(std::integral_constant<int, 1>{});
+        else pingpong(std::integral_constant<int, 2>{});
+    } else
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        const bool has_next = kt + 1 < nk;
-        if (has_next && (p.stagger == 0 || (p.stagger == 1 && late_wave == 0))) stage(kt + 1, cur ^ 1);
+        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
         const char* base = smem + cur * BUF_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            if (ks == 2 && has_next && p.stagger == 1 && late_wave != 0) stage(kt + 1, cur ^ 1);
-            if (has_next && p.stagger == 2) stage_quarter(kt + 1, cur ^ 1, ks);
             bf16x8 wf[NT], xf[MT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) wf[nt] = *(const bf16x8*)(base + w_row_base + nt * 4096 + chunk_off[ks]);

@@ -46,8 +46,10 @@ int aether_check_device(void);
 #define AETHER_EPI_BIAS_GELU 1     /* C = gelu_tanh(A·Wᵀ + bias)                                 */
 #define AETHER_EPI_BIAS_GATE_RES 2 /* C = R + gate[b(m),type(m),:] ⊙ (A·Wᵀ + bias)               */
 #define AETHER_GEMM_WIDE_STORE 1   /* flags bit: 16-byte stores through a half-wave exchange      */
-#define AETHER_GEMM_STAGGER(mode) (((mode) & 3) << 2) /* flags bits 2-3 (GEMM): LDS-DMA issue placement inside a K tile:
-                                      0 all up front, 1 second wave of each SIMD issues mid-tile, 2 a quarter per k-step */
+#define AETHER_GEMM_PINGPONG 4      /* flags bit 2: ping-pong main loop — the two waves that share a SIMD alternate
+                                      "read fragments from LDS" and "issue MFMAs" slots, phase-locked by s_barrier, LDS-DMA
+                                      issued in the MFMA shadow (+8..12 % over the lock-step loop on MI355X)              */
+#define AETHER_GEMM_PINGPONG2 8     /* flags bit 3 (instead of bit 2): same with two k-steps per slot                     */
 
 /* C[M,N] = epi(A[M,K] · W[N,K]ᵀ), bf16 in / bf16 out / fp32 accumulate on MFMA.
  * Replaces nn.Linear in CogVideoXBlock / CogVideoXPatchEmbed / proj_out under P:865-875

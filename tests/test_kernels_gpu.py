@@ -28,7 +28,7 @@ def _bf16_close(got, ref_fp32, what, rel=6e-3, max_ulp_frac=2.0):
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 256), (300, 256, 128), (1000, 512, 3072), (226, 512, 4096), (37, 224, 512)])
-@pytest.mark.parametrize("flags", [0, 1, 1 | (1 << 2), 1 | (2 << 2)])     # bits 2-3: LDS-DMA issue placement variants
+@pytest.mark.parametrize("flags", [0, 1, 1 | 4, 1 | 8, 4])     # bit 0: 16-byte stores; bits 2/3: ping-pong main loop (1 / 2 k-steps per slot)
 def test_gemm_bias(cuda, hip_lib, M, N, K, flags):
     from aether_amd import ops
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
@@ -52,7 +52,7 @@ def test_gemm_transpose_detecting(cuda, hip_lib):
     assert torch.equal(out.cpu().float(), W.float().t())
 
 
-@pytest.mark.parametrize("flags", [0, 1])
+@pytest.mark.parametrize("flags", [0, 5])
 def test_gemm_gelu(cuda, hip_lib, flags):
     from aether_amd import ops
     g = torch.Generator().manual_seed(5)
@@ -66,7 +66,7 @@ def test_gemm_gelu(cuda, hip_lib, flags):
     _bf16_close(out, ref, "gemm+gelu")
 
 
-@pytest.mark.parametrize("flags", [0, 1])
+@pytest.mark.parametrize("flags", [0, 5, 9])
 def test_gemm_gate_residual_inplace(cuda, hip_lib, flags):
     from aether_amd import ops
     g = torch.Generator().manual_seed(6)

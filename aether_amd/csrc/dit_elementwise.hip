@@ -168,13 +168,14 @@ __global__ void unpatchify_kernel(const unsigned short* __restrict__ Y, int ldy,
 }
 
 // ------------------------------------------------------------------------------------------------
-// q/k LayerNorm(64) + RoPE + scale -> head-major Qh/Kh.  One block per token row; 8 lanes per (part, head).
+// q/k LayerNorm(64) + RoPE + scale -> head-major Qh/Kh (+ max ||k||^2 per head).  One block per token row; 8 lanes per (part, head).
 // ------------------------------------------------------------------------------------------------
 struct QkArgs {
     const bf16_t* qkv; int S, H, n_text;
     const float* qn_w; const float* qn_b; const float* kn_w; const float* kn_b; float eps;
     const float* cos_t; const float* sin_t; float q_scale;
     bf16_t* Qh; bf16_t* Kh;
+    float* kmax2;   // [B*H] running max of ||k||^2 (atomic), or null
 };
 
 __global__ __launch_bounds__(256) void qk_norm_rope_kernel(QkArgs p) {
@@ -215,6 +216,16 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(QkArgs p) {
             }
         }
         const float sc = (part == 0) ? p.q_scale : 1.0f;
+        if (p.kmax2 != nullptr && part == 1) {
+            // ||k||^2 of this (token, head): 8 lanes hold 8 elements each.  Non-negative floats order like their bit
+            // patterns, so an unsigned atomicMax works; the (possibly stale) plain read only filters the atomics.
+            float n2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) n2 += v[e] * v[e];
+            n2 += __shfl_xor(n2, 1, 64); n2 += __shfl_xor(n2, 2, 64); n2 += __shfl_xor(n2, 4, 64);
+            float* slot = p.kmax2 + (size_t)b * p.H + h;
+            if (sub == 0 && n2 > __builtin_nontemporal_load(slot)) atomicMax((unsigned*)slot, __float_as_uint(n2));
+        }
         uint4 out = make_uint4(pack_bf16x2(v[0] * sc, v[1] * sc), pack_bf16x2(v[2] * sc, v[3] * sc),
                                pack_bf16x2(v[4] * sc, v[5] * sc), pack_bf16x2(v[6] * sc, v[7] * sc));
         bf16_t* dst = (part == 0 ? p.Qh : p.Kh) + (((size_t)b * p.H + h) * p.S + s) * 64 + sub * 8;
@@ -318,12 +329,12 @@ extern "C" int aether_unpatchify(const void* Y, int ldy, void* out, int B, int F
 
 extern "C" int aether_qk_norm_rope(const void* qkv, int B, int S, int H, int n_text, const float* qn_w, const float* qn_b,
                                    const float* kn_w, const float* kn_b, float eps, const float* cos_t, const float* sin_t,
-                                   float q_scale, void* Qh, void* Kh, void* Vt, int Spad, void* stream) {
+                                   float q_scale, void* Qh, void* Kh, void* Vt, int Spad, float* kmax2, void* stream) {
     if (!qkv || !Qh || !Kh || !Vt || !qn_w || !qn_b || !kn_w || !kn_b) return aether_set_error(AETHER_ERR_ARG, "qk_norm_rope: null pointer");
     if (B <= 0 || S <= 0 || H <= 0 || n_text < 0 || n_text > S) return aether_set_error(AETHER_ERR_SHAPE, "qk_norm_rope: bad shape");
     if (n_text < S && (!cos_t || !sin_t)) return aether_set_error(AETHER_ERR_ARG, "qk_norm_rope: rope tables required");
     if (Spad % 64 != 0 || Spad < S) return aether_set_error(AETHER_ERR_SHAPE, "qk_norm_rope: Spad must be roundup(S,64)");
-    QkArgs p{(const bf16_t*)qkv, S, H, n_text, qn_w, qn_b, kn_w, kn_b, eps, cos_t, sin_t, q_scale, (bf16_t*)Qh, (bf16_t*)Kh};
+    QkArgs p{(const bf16_t*)qkv, S, H, n_text, qn_w, qn_b, kn_w, kn_b, eps, cos_t, sin_t, q_scale, (bf16_t*)Qh, (bf16_t*)Kh, kmax2};
     hipLaunchKernelGGL(qk_norm_rope_kernel, dim3(B * S), dim3(256), 0, AE_STREAM, p);
     int rc = aether_check_launch("qk_norm_rope");
     if (rc) return rc;

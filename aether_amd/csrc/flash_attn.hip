@@ -2,21 +2,36 @@
 // (S = 226 + 14 850 tokens at the BASELINE shape).  Replaces F.scaled_dot_product_attention inside diffusers'
 // CogVideoXAttnProcessor2_0, reached from aether/pipelines/aetherv1_pipeline_cogvideox.py:865-875.
 //
-// gfx950 design
-//   * workgroup = 8 wavefronts = 256 query rows (32 per wave), KV tile = 64 keys, one barrier per KV tile;
-//     K [64 keys][64 d] and Vᵀ [64 d][64 keys] tiles arrive by 16-byte LDS-DMA, double buffered (32 KiB LDS),
-//     128-byte rows XOR-swizzled on the DMA source address so every ds_read_b128 is conflict free.
+// Contract: Qh carries softmax_scale·log2(e) (aether_qk_norm_rope folds it into the fp32 value before the single
+// rounding to bf16), so a score s = q·k is already in the log2 domain and p = exp2(s − m).
+//
+// gfx950 design (both kernels)
+//   * workgroup = 8 wavefronts = 256 query rows (32 per wave), KV tile = 64 keys;
+//     K [64 keys][64 d] and Vᵀ [64 d][64 keys] tiles arrive by 16-byte LDS-DMA; 128-byte rows XOR-swizzled on the
+//     DMA source address so every ds_read_b128 is conflict free.
 //   * "swapped" QKᵀ: S^T = K·Qᵀ on v_mfma_f32_32x32x16_bf16, so one lane holds 32 of the 64 scores of ONE
-//     query row; the row maximum costs 31 in-lane max + one half-wave exchange and the soft-max runs
-//     entirely in registers.  K rows enter the MFMA through a fixed permutation (pi below) chosen so the
-//     exponentiated scores of a lane are, in register order, exactly the B-operand fragment of the P·V MFMA
-//     (8 consecutive keys per 16-key slab) — no cross-lane movement of P.
+//     query row; the soft-max runs entirely in registers.  K rows enter the MFMA through a fixed permutation (pi
+//     below) chosen so the exponentiated scores of a lane are, in register order, exactly the B-operand fragment of
+//     the P·V MFMA (8 consecutive keys per 16-key slab) — no cross-lane movement of P.
 //   * V is consumed transposed (Vᵀ is produced once per layer by aether_qk_norm_rope), so its A-operand
 //     fragment is a plain 16-byte row read.
-//   * exp2 domain: p = exp2(s·log2e − m), one fma + one v_exp_f32 per score; the O/l rescale is skipped by a
-//     wave-uniform branch whenever no row maximum grew (exact, no threshold).
+//   * bounded-score fast path: at head_dim 64 the kernel is VALU-issue bound (≈5 VALU slots per score against
+//     16 MFMAs per 2048 scores), so the biggest lever is fewer VALU ops per score.  q and k are LayerNorm outputs,
+//     so |q·k| ≤ ‖q‖·max‖k‖ (Cauchy–Schwarz); aether_qk_norm_rope emits max‖k‖² per (batch, head).  When that bound
+//     is ≤ 64 for every row of a wave, exp2(s) can neither overflow nor underflow in fp32/bf16 and soft-max is
+//     shift invariant, so the wave runs p = exp2(s) with NO running maximum, NO subtraction and NO rescale
+//     (1 v_exp + 1 v_add + ½ v_cvt_pk per score).  Otherwise (or when no bound is supplied) it runs the exact
+//     online soft-max with the conditional rescale.  The decision is per wave and wave-uniform.
 //   * workgroups are remapped so that one XCD walks the query blocks of one (batch, head) consecutively:
 //     its K/V (3.9 MB at S = 15 076) stays in that XCD's 4 MiB L2.
+//
+// flash_attn_fwd_kernel: one barrier per KV tile, all 8 waves in lock step, 2 workgroups per CU (TLP hides latency).
+// flash_attn_pp_kernel ("ping-pong"): one workgroup per CU; the two waves that share a SIMD (w, w+4) alternate,
+//   phase-locked by s_barrier, between an MFMA stage (P·V of tile j and K·Qᵀ of tile j+1: 16 back-to-back MFMAs fed
+//   purely from registers) and a VALU stage (soft-max of tile j+1, the 16 ds_read_b128 of the next fragments, the
+//   LDS-DMA of tile j+4) — the matrix pipe of every SIMD always has one wave feeding it while its partner does
+//   the soft-max.  4-deep K/V ring in LDS (64 KiB), DMA waits are counted (vmcnt(2)), never drained in the loop.
+#include <type_traits>
 #include "common.hpp"
 #include "../../include/aether_hip.h"
 
@@ -25,104 +40,63 @@ namespace aether {
 constexpr int FA_QBLK = 256, FA_KVBLK = 64, FA_D = 64;
 constexpr int FA_TILE = FA_KVBLK * FA_D * 2;  // 8 KiB (K tile) == 8 KiB (Vᵀ tile)
 constexpr int FA_BUF = 2 * FA_TILE;
+constexpr float FA_FAST_BOUND2 = 64.f * 64.f;  // (‖q‖·max‖k‖)² limit of the bounded-score path
+constexpr float FA_BOUND_SLACK = 1.02f;        // covers the bf16 rounding of k after its norm was taken (2^-8 rel.)
 
 struct FlashArgs {
     const bf16_t* Q; const bf16_t* K; const bf16_t* Vt; bf16_t* O;
+    const float* kmax2;   // [B*H] upper bound of ‖k‖² per (batch, head), or null
     int H, S, Spad, nqb, nwg;
 };
 
-template <bool WIDE_STORE>
-__global__ __launch_bounds__(512) void flash_attn_fwd_kernel(FlashArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * FA_BUF];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l32 = lane & 31;
+// ---- pieces shared by the two kernels ---------------------------------------------------------------------------
+struct FaLane {
+    int lane, wave, hi, l32;
+    int koff[4];      // K fragment byte offsets inside a tile (+ t*4096)
+    int voff[2][2];   // Vᵀ fragment byte offsets inside a buffer (+ dt*4096), includes FA_TILE
+};
 
-    const int wgid = xcd_remap(blockIdx.x, p.nwg);
-    const int bh = wgid / p.nqb;
-    const int qb = wgid - bh * p.nqb;
-    const int S = p.S;
-
-    const bf16_t* Qg = p.Q + (size_t)bh * S * FA_D;
-    const bf16_t* Kg = p.K + (size_t)bh * S * FA_D;
-    const bf16_t* Vg = p.Vt + (size_t)bh * FA_D * p.Spad;
-
-    // ---- Q fragment (B operand): lane (q = l32, hi) holds Q[q][16ks + 8hi .. +7] -------------------
-    const int qrow = qb * FA_QBLK + wave * 32 + l32;
-    const int qrow_c = min(qrow, S - 1);
-    bf16x8 qf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(Qg + (size_t)qrow_c * FA_D + 16 * ks + 8 * hi);
-
-    // ---- staging (one 16-byte piece of K and one of Vᵀ per thread per KV tile) ---------------------
-    const int srow = tid >> 3;                          // K: key row in tile; Vᵀ: d row
-    const int schunk = (tid & 7) ^ ((srow >> 1) & 7);   // logical chunk fetched into physical chunk tid&7
-    char* const lds_stage = smem + wave * 1024;
-    const bf16_t* const vsrc = Vg + (size_t)srow * p.Spad + schunk * 8;
-    auto stage = [&](int j, int buf) {
-        const int krow = min(j * FA_KVBLK + srow, S - 1);
-        glds16(Kg + (size_t)krow * FA_D + schunk * 8, lds_stage + buf * FA_BUF);
-        glds16(vsrc + j * FA_KVBLK, lds_stage + buf * FA_BUF + FA_TILE);
-    };
-
-    // ---- fragment read offsets ---------------------------------------------------------------------
+AE_DEV FaLane fa_lane_setup() {
+    FaLane L;
+    const int tid = threadIdx.x;
+    L.lane = tid & 63; L.wave = tid >> 6; L.hi = L.lane >> 5; L.l32 = L.lane & 31;
     // K row fed to MFMA row i (= l32):  pi(i) = 16*(a>>1) + 8*h + 4*(a&1) + c,  i = 8a + 4h + c
-    const int a_ = l32 >> 3, h_ = (l32 >> 2) & 1, c_ = l32 & 3;
+    const int a_ = L.l32 >> 3, h_ = (L.l32 >> 2) & 1, c_ = L.l32 & 3;
     const int pi = 16 * (a_ >> 1) + 8 * h_ + 4 * (a_ & 1) + c_;
     const int kswz = (pi >> 1) & 7;
-    int koff[4];  // + t*32*128
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) koff[ks] = pi * 128 + (((2 * ks + hi) ^ kswz) << 4);
-    const int vswz = (l32 >> 1) & 7;
-    int voff[2][2];  // [t][s], + dt*32*128; chunk = 4t + 2s + hi
+    for (int ks = 0; ks < 4; ++ks) L.koff[ks] = pi * 128 + (((2 * ks + L.hi) ^ kswz) << 4);
+    const int vswz = (L.l32 >> 1) & 7;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) voff[t][s] = FA_TILE + l32 * 128 + (((4 * t + 2 * s + hi) ^ vswz) << 4);
+        for (int s = 0; s < 2; ++s) L.voff[t][s] = FA_TILE + L.l32 * 128 + (((4 * t + 2 * s + L.hi) ^ vswz) << 4);  // chunk = 4t+2s+hi
+    return L;
+}
 
-    f32x16 o[2];
+// keys >= S of the ragged last tile score -inf.  sc[t][r] = score(q = l32, key = 64j + 32t + 16(r>>3) + 8hi + (r&7))
+AE_DEV void fa_mask_tail(f32x16 (&sc)[2], int j, int hi, int S) {
+    const int kb = j * FA_KVBLK + 8 * hi;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
-    float m_run = -INFINITY;  // running row maximum, log2 domain (shared by the two lanes of a row)
-    float l_run = 0.f;        // this lane's partial row sum
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (kb + 32 * t + 16 * (r >> 3) + (r & 7) >= S) sc[t][r] = -INFINITY;
+}
 
-    const float LOG2E = 1.4426950408889634f;
-    const int nkv = (S + FA_KVBLK - 1) / FA_KVBLK;
-    stage(0, 0);
-    drain_and_barrier();
-
-    for (int j = 0; j < nkv; ++j) {
-        const int cur = j & 1;
-        if (j + 1 < nkv) stage(j + 1, cur ^ 1);
-        const char* base = smem + cur * FA_BUF;
-
-        // S^T tiles: sc[t][r] = score(q = l32, key = 64j + 32t + 16(r>>3) + 8hi + (r&7))
-        f32x16 sc[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sc[t][i] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kf = *(const bf16x8*)(base + t * 4096 + koff[ks]);
-                sc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[t], 0, 0, 0);
-            }
-        }
-        if (j == nkv - 1 && (S & (FA_KVBLK - 1))) {  // ragged last tile: keys >= S score -inf
-            const int kb = j * FA_KVBLK + 8 * hi;
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (kb + 32 * t + 16 * (r >> 3) + (r & 7) >= S) sc[t][r] = -INFINITY;
-        }
-
-        // ---- online softmax ----
+// soft-max of one 32 x 64 score tile held as sc[2] -> bf16 P fragments pf[t][s] (B operand of P·V).
+// FAST: p = exp2(s), no maximum.  Otherwise exact online soft-max: m_run/l_run/o are rescaled when a row maximum grew.
+template <bool FAST>
+AE_DEV void fa_softmax(const f32x16 (&sc)[2], bf16x8 (&pf)[2][2], f32x16 (&o)[2], float& m_run, float& l_run) {
+    float shift = 0.f;
+    if (!FAST) {
         float mx = sc[0][0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[0][r]);
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[1][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx * LOG2E);
+        const float m_new = fmaxf(m_run, mx);
         if (__any(m_new > m_run)) {
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // 0 on the first tile (m_run = -inf)
 #pragma unroll
@@ -130,42 +104,47 @@ __global__ __launch_bounds__(512) void flash_attn_fwd_kernel(FlashArgs p) {
             l_run *= alpha;
             m_run = m_new;
         }
-        float psum = 0.f;
-        bf16x8 pf[2][2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                float pv[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    pv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[t][8 * s + e], LOG2E, -m_run));
-                    psum += pv[e];
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) pf[t][s][e] = (__bf16)pv[e];
-            }
-        l_run += psum;
-
-        // ---- O^T += Vᵀ · Pᵀ ----
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const bf16x8 vf = *(const bf16x8*)(base + dt * 4096 + voff[t][s]);
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[t][s], o[dt], 0, 0, 0);
-                }
-        drain_and_barrier();
+        shift = m_run;
     }
+    float psum[4] = {0.f, 0.f, 0.f, 0.f};   // four independent add chains
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float pv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                pv[e] = __builtin_amdgcn_exp2f(FAST ? sc[t][8 * s + e] : sc[t][8 * s + e] - shift);
+                psum[e & 3] += pv[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[t][s][e] = (__bf16)pv[e];
+        }
+    l_run += (psum[0] + psum[1]) + (psum[2] + psum[3]);
+}
 
-    // ---- epilogue: O[q][h*64 + d], d = 32dt + 8(r>>2) + 4hi + (r&3) ---------------------------------
+// per-wave decision: every row of this wave has (‖q‖·max‖k‖)² within the bounded-score limit
+AE_DEV bool fa_fast_ok(const bf16x8 (&qf)[4], const float* kmax2, int bh) {
+    if (kmax2 == nullptr) return false;
+    float qn2 = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float q = (float)qf[ks][e]; qn2 += q * q; }
+    qn2 += __shfl_xor(qn2, 32, 64);
+    const float km = kmax2[bh];
+    return __all(qn2 * km * FA_BOUND_SLACK <= FA_FAST_BOUND2) != 0;
+}
+
+// epilogue: O[q][h*64 + d], d = 32dt + 8(r>>2) + 4hi + (r&3)
+template <bool WIDE_STORE>
+AE_DEV void fa_store(const f32x16 (&o)[2], float l_run, const FlashArgs& p, int bh, int qrow, int hi) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     const int b = bh / p.H, h = bh - b * p.H;
-    const bool q_ok = qrow < S;
-    bf16_t* orow = p.O + ((size_t)b * S + qrow_c) * (size_t)(p.H * FA_D) + h * FA_D;
+    const bool q_ok = qrow < p.S;
+    const int qrow_c = min(qrow, p.S - 1);
+    bf16_t* orow = p.O + ((size_t)b * p.S + qrow_c) * (size_t)(p.H * FA_D) + h * FA_D;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
         unsigned pk[4][2];
@@ -189,12 +168,241 @@ __global__ __launch_bounds__(512) void flash_attn_fwd_kernel(FlashArgs p) {
     }
 }
 
+// =================================================================================================================
+// lock-step kernel: one barrier per KV tile, double-buffered LDS (32 KiB), 2 workgroups per CU
+// =================================================================================================================
+template <bool WIDE_STORE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))   // <= 128 VGPRs: two workgroups per CU
+void flash_attn_fwd_kernel(FlashArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * FA_BUF];
+    const FaLane L = fa_lane_setup();
+    const int tid = threadIdx.x, hi = L.hi;
+
+    const int wgid = xcd_remap(blockIdx.x, p.nwg);
+    const int bh = wgid / p.nqb;
+    const int qb = wgid - bh * p.nqb;
+    const int S = p.S;
+
+    const bf16_t* Qg = p.Q + (size_t)bh * S * FA_D;
+    const bf16_t* Kg = p.K + (size_t)bh * S * FA_D;
+    const bf16_t* Vg = p.Vt + (size_t)bh * FA_D * p.Spad;
+
+    // ---- Q fragment (B operand): lane (q = l32, hi) holds Q[q][16ks + 8hi .. +7] -------------------
+    const int qrow = qb * FA_QBLK + L.wave * 32 + L.l32;
+    const int qrow_c = min(qrow, S - 1);
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(Qg + (size_t)qrow_c * FA_D + 16 * ks + 8 * hi);
+
+    // ---- staging (one 16-byte piece of K and one of Vᵀ per thread per KV tile) ---------------------
+    const int srow = tid >> 3;                          // K: key row in tile; Vᵀ: d row
+    const int schunk = (tid & 7) ^ ((srow >> 1) & 7);   // logical chunk fetched into physical chunk tid&7
+    char* const lds_stage = smem + L.wave * 1024;
+    const bf16_t* const vsrc = Vg + (size_t)srow * p.Spad + schunk * 8;
+    auto stage = [&](int j, int buf) {
+        const int krow = min(j * FA_KVBLK + srow, S - 1);
+        glds16(Kg + (size_t)krow * FA_D + schunk * 8, lds_stage + buf * FA_BUF);
+        glds16(vsrc + j * FA_KVBLK, lds_stage + buf * FA_BUF + FA_TILE);
+    };
+
+    f32x16 o[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+    float m_run = -INFINITY;  // running row maximum, log2 domain (shared by the two lanes of a row)
+    float l_run = 0.f;        // this lane's partial row sum
+
+    const int nkv = (S + FA_KVBLK - 1) / FA_KVBLK;
+    const bool ragged = (S & (FA_KVBLK - 1)) != 0;
+    stage(0, 0);
+    const bool fast = fa_fast_ok(qf, p.kmax2, bh);
+    drain_and_barrier();
+
+    auto sweep = [&](auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        for (int j = 0; j < nkv; ++j) {
+            const int cur = j & 1;
+            if (j + 1 < nkv) stage(j + 1, cur ^ 1);
+            const char* base = smem + cur * FA_BUF;
+
+            f32x16 sc[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sc[t][i] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 kf = *(const bf16x8*)(base + t * 4096 + L.koff[ks]);
+                    sc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[t], 0, 0, 0);
+                }
+            }
+            if (j == nkv - 1 && ragged) fa_mask_tail(sc, j, hi, S);
+
+            bf16x8 pf[2][2];
+            fa_softmax<FAST>(sc, pf, o, m_run, l_run);
+
+            // ---- O^T += Vᵀ · Pᵀ ----
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const bf16x8 vf = *(const bf16x8*)(base + dt * 4096 + L.voff[t][s]);
+                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[t][s], o[dt], 0, 0, 0);
+                    }
+            drain_and_barrier();
+        }
+    };
+    if (fast) sweep(std::true_type{});
+    else sweep(std::false_type{});
+
+    fa_store<WIDE_STORE>(o, l_run, p, bh, qrow, hi);
+}
+
+// =================================================================================================================
+// ping-pong kernel: one workgroup per CU, waves w and w+4 (same SIMD) alternate MFMA stage / soft-max stage
+// =================================================================================================================
+constexpr int FA_NB = 4;  // K/V ring depth
+
+// PRIO: 0 no priority, 1 the MFMA stage runs at s_setprio 1, 2 the soft-max stage runs at s_setprio 1
+template <bool WIDE_STORE, int PRIO>
+__global__ __launch_bounds__(512) void flash_attn_pp_kernel(FlashArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[FA_NB * FA_BUF];
+    const FaLane L = fa_lane_setup();
+    const int tid = threadIdx.x, hi = L.hi;
+    const int grp = __builtin_amdgcn_readfirstlane(L.wave >> 2);   // waves 4-7 share SIMDs with waves 0-3
+
+    const int wgid = xcd_remap(blockIdx.x, p.nwg);
+    const int bh = wgid / p.nqb;
+    const int qb = wgid - bh * p.nqb;
+    const int S = p.S;
+
+    const bf16_t* Qg = p.Q + (size_t)bh * S * FA_D;
+    const bf16_t* Kg = p.K + (size_t)bh * S * FA_D;
+    const bf16_t* Vg = p.Vt + (size_t)bh * FA_D * p.Spad;
+
+    const int qrow = qb * FA_QBLK + L.wave * 32 + L.l32;
+    const int qrow_c = min(qrow, S - 1);
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(Qg + (size_t)qrow_c * FA_D + 16 * ks + 8 * hi);
+
+    const int srow = tid >> 3;
+    const int schunk = (tid & 7) ^ ((srow >> 1) & 7);
+    char* const lds_stage = smem + L.wave * 1024;
+    const bf16_t* const vsrc = Vg + (size_t)srow * p.Spad + schunk * 8;
+    const int nkv = (S + FA_KVBLK - 1) / FA_KVBLK;
+    // tile j -> ring slot j & 3.  Tiles past the end re-fetch the last tile into a slot nobody reads any more: the main
+    // loop stays branch free (uniform vmcnt accounting) at the price of <= 3 redundant tile loads per workgroup.
+    auto stage = [&](int j) {
+        const int buf = j & (FA_NB - 1);
+        const int jc = min(j, nkv - 1);
+        const int krow = min(jc * FA_KVBLK + srow, S - 1);
+        glds16(Kg + (size_t)krow * FA_D + schunk * 8, lds_stage + buf * FA_BUF);
+        glds16(vsrc + jc * FA_KVBLK, lds_stage + buf * FA_BUF + FA_TILE);
+    };
+
+    f32x16 o[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const bool ragged = (S & (FA_KVBLK - 1)) != 0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) stage(t);
+    const bool fast = fa_fast_ok(qf, p.kmax2, bh);
+    drain_and_barrier();
+
+    auto slot_end = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    auto sweep = [&](auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        bf16x8 kf[2][4], vf[2][2][2], pf[2][2];
+        f32x16 sc[2];
+        auto load_k = [&](int j) {
+            const char* base = smem + (j & (FA_NB - 1)) * FA_BUF;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) kf[t][ks] = *(const bf16x8*)(base + t * 4096 + L.koff[ks]);
+        };
+        auto load_v = [&](int j) {
+            const char* base = smem + (j & (FA_NB - 1)) * FA_BUF;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) vf[dt][t][s] = *(const bf16x8*)(base + dt * 4096 + L.voff[t][s]);
+        };
+        auto qk = [&]() {   // sc = K(j+1)·Qᵀ : 8 MFMAs alternating the two accumulators
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { sc[0][i] = 0.f; sc[1][i] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) sc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t][ks], qf[ks], sc[t], 0, 0, 0);
+        };
+        auto pv = [&]() {   // o += Vᵀ(j)·Pᵀ(j) : 8 MFMAs alternating the two accumulators
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][t][s], pf[t][s], o[dt], 0, 0, 0);
+        };
+
+        // Slot schedule (B = s_barrier).  group 0:  P0 B (V0 B M0 B) (V1 B M1 B) ... B      P0 = K(0)·Qᵀ
+        //                                  group 1:  B P0 B (V0 B M0 B) ...                   (one slot behind)
+        //   Vj: reads Vᵀ(j), K(j+1) fragments; issues the DMA of tile j+3; soft-max of tile j; waits for tile j+2
+        //   Mj: P·V of tile j and K(j+1)·Qᵀ, registers only (past the last tile the K·Qᵀ result is simply unused)
+        // Ring safety: slot (j+3)&3 last held tile j-1, whose last read (Vᵀ(j-1)) was in V(j-1) of either group, two or
+        // more barriers earlier; tile j+2 was issued in V(j-1) and is waited for (vmcnt(2)) before the barrier ending
+        // Vj, so every wave's piece has landed before any wave reads K(j+2) in V(j+1) / Vᵀ(j+2) in V(j+2).
+        load_k(0);
+        wait_lgkmcnt0();
+        if (grp) slot_end();
+        if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
+        qk();
+        if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
+        slot_end();
+        for (int j = 0; j < nkv; ++j) {
+            if (PRIO == 2) __builtin_amdgcn_s_setprio(1);
+            load_v(j);
+            load_k(j + 1);
+            stage(j + 3);
+            if (j == nkv - 1 && ragged) fa_mask_tail(sc, j, hi, S);
+            fa_softmax<FAST>(sc, pf, o, m_run, l_run);
+            __builtin_amdgcn_sched_barrier(0);   // the soft-max VALU stays in THIS stage, ahead of the wait
+            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+            if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
+            slot_end();
+            if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
+            pv();
+            qk();
+            if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
+            slot_end();
+        }
+        if (!grp) slot_end();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant tail DMA must not outlive the workgroup's LDS
+    };
+    if (fast) sweep(std::true_type{});
+    else sweep(std::false_type{});
+
+    fa_store<WIDE_STORE>(o, l_run, p, bh, qrow, hi);
+}
+
 }  // namespace aether
 
 using namespace aether;
 
 extern "C" int aether_flash_attn_fwd(const void* Qh, const void* Kh, const void* Vt, void* O, int B, int H, int S,
-                                     int Spad, int flags, void* stream) {
+                                     int Spad, const float* kmax2, int flags, void* stream) {
     if (!Qh || !Kh || !Vt || !O) return aether_set_error(AETHER_ERR_ARG, "flash_attn: null pointer");
     if (B <= 0 || H <= 0 || S <= 0) return aether_set_error(AETHER_ERR_SHAPE, "flash_attn: empty problem");
     if (Spad % FA_KVBLK != 0 || Spad < S) return aether_set_error(AETHER_ERR_SHAPE, "flash_attn: Spad must be roundup(S,64)");
@@ -202,13 +410,23 @@ extern "C" int aether_flash_attn_fwd(const void* Qh, const void* Kh, const void*
         return aether_set_error(AETHER_ERR_ALIGN, "flash_attn: pointers must be 16-byte aligned");
     FlashArgs p;
     p.Q = (const bf16_t*)Qh; p.K = (const bf16_t*)Kh; p.Vt = (const bf16_t*)Vt; p.O = (bf16_t*)O;
+    p.kmax2 = (flags & AETHER_ATTN_EXACT_MAX) ? nullptr : kmax2;
     p.H = H; p.S = S; p.Spad = Spad;
     p.nqb = (S + FA_QBLK - 1) / FA_QBLK;
     p.nwg = p.nqb * B * H;
     hipStream_t s = (hipStream_t)stream;
-    if (flags & AETHER_GEMM_WIDE_STORE)
-        hipLaunchKernelGGL((flash_attn_fwd_kernel<true>), dim3(p.nwg), dim3(512), 0, s, p);
-    else
-        hipLaunchKernelGGL((flash_attn_fwd_kernel<false>), dim3(p.nwg), dim3(512), 0, s, p);
+    const bool wide = (flags & AETHER_GEMM_WIDE_STORE) != 0;
+    dim3 grid(p.nwg), block(512);
+    if (flags & AETHER_ATTN_PINGPONG) {
+        const int prio = (flags >> 6) & 3;
+#define FA_PP(W, P) hipLaunchKernelGGL((flash_attn_pp_kernel<W, P>), grid, block, 0, s, p)
+        if (wide) { if (prio == 1) FA_PP(true, 1); else if (prio == 2) FA_PP(true, 2); else FA_PP(true, 0); }
+        else      { if (prio == 1) FA_PP(false, 1); else if (prio == 2) FA_PP(false, 2); else FA_PP(false, 0); }
+#undef FA_PP
+    } else if (wide) {
+        hipLaunchKernelGGL((flash_attn_fwd_kernel<true>), grid, block, 0, s, p);
+    } else {
+        hipLaunchKernelGGL((flash_attn_fwd_kernel<false>), grid, block, 0, s, p);
+    }
     return aether_check_launch("flash_attn_fwd");
 }

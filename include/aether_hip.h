@@ -95,16 +95,29 @@ int aether_unpatchify(const void* Y, int ldy, void* out, int B, int F, int Cout,
  * norm_q/norm_k + apply_rotary_emb (adjacent-pair convention, fp32) under P:865-875.
  * qkv bf16 [B,S,3*H*64] (q | k | v thirds) -> Qh,Kh bf16 [B,H,S,64] and Vt bf16 [B,H,64,Spad]
  * (V transposed, Spad = roundup(S,64), pad columns zeroed).  Rows [0,n_text) of each batch are text rows
- * (no RoPE); cos,sin fp32 [S-n_text, 64].  Q is additionally multiplied by q_scale (1/sqrt(64), exact in bf16). */
+ * (no RoPE); cos,sin fp32 [S-n_text, 64].  Q is additionally multiplied by q_scale in fp32 before its single rounding
+ * to bf16; the attention kernel expects q_scale = log2(e)/sqrt(64) (scores in the log2 domain).
+ * kmax2 (fp32 [B*H], may be NULL): atomically max-accumulates ||k||^2 of every (batch, head) — the caller zeroes it
+ * beforehand; it feeds the bounded-score path of aether_flash_attn_fwd. */
 int aether_qk_norm_rope(const void* qkv, int B, int S, int H, int n_text, const float* qn_w, const float* qn_b,
                         const float* kn_w, const float* kn_b, float eps, const float* cos_t, const float* sin_t,
-                        float q_scale, void* Qh, void* Kh, void* Vt, int Spad, void* stream);
+                        float q_scale, void* Qh, void* Kh, void* Vt, int Spad, float* kmax2, void* stream);
 
-/* Non-causal flash attention, head_dim 64: O[b,s,h*64+d] = softmax(Qh·Khᵀ)·V  (scale pre-folded into Qh).
- * Replaces F.scaled_dot_product_attention in CogVideoXAttnProcessor2_0.  Qh,Kh [B,H,S,64], Vt [B,H,64,Spad],
- * O bf16 [B,S,H*64].  flags: AETHER_GEMM_WIDE_STORE selects the 16-byte epilogue store. */
+#define AETHER_ATTN_PINGPONG 16   /* flags bit 4: ping-pong kernel (one workgroup per CU, the two waves of a SIMD alternate
+                                     an MFMA stage and a soft-max stage)                                                  */
+#define AETHER_ATTN_EXACT_MAX 32  /* flags bit 5: ignore kmax2, always run the exact online soft-max                      */
+#define AETHER_ATTN_PRIO_MFMA 64  /* flags bits 6-7 (ping-pong only): 1 = s_setprio 1 in the MFMA stage, 2 = in the      */
+#define AETHER_ATTN_PRIO_VALU 128 /*                                   soft-max stage, 0 = no priority                    */
+
+/* Non-causal flash attention, head_dim 64: O[b,s,h*64+d] = softmax_2(Qh·Khᵀ)·V where softmax_2 uses base 2, i.e.
+ * Qh must carry softmax_scale·log2(e) (see aether_qk_norm_rope).  Replaces F.scaled_dot_product_attention in
+ * CogVideoXAttnProcessor2_0.  Qh,Kh [B,H,S,64], Vt [B,H,64,Spad], O bf16 [B,S,H*64].
+ * kmax2 (fp32 [B*H] or NULL): upper bound of ||k||^2 per (batch, head).  A wave whose rows all satisfy
+ * ||q||·sqrt(kmax2) <= 64 runs soft-max without the running maximum (scores are bounded, exp2 cannot overflow or
+ * underflow, soft-max is shift invariant); every other wave, and every wave when kmax2 is NULL, runs the exact online
+ * soft-max.  flags: AETHER_GEMM_WIDE_STORE (16-byte epilogue stores), AETHER_ATTN_*. */
 int aether_flash_attn_fwd(const void* Qh, const void* Kh, const void* Vt, void* O, int B, int H, int S, int Spad,
-                          int flags, void* stream);
+                          const float* kmax2, int flags, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * 3D-causal VAE kernels (diffusers AutoencoderKLCogVideoX: encode at P:557-618, decode_latents at P:931,936).

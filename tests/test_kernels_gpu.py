@@ -186,39 +186,90 @@ def _qk_ref(qkv, H, n_text, qn_w, qn_b, kn_w, kn_b, cos, sin):
 @pytest.mark.parametrize("B,H,S,n_text", [(1, 2, 100, 10), (2, 3, 333, 226), (1, 1, 64, 0)])
 def test_qk_norm_rope(cuda, hip_lib, B, H, S, n_text):
     from aether_amd import ops
+    from aether_amd._lib import ATTN_Q_SCALE
     qkv, qn_w, qn_b, kn_w, kn_b, cos, sin = _attn_inputs(B, H, S, n_text, 11)
     q, k, v = _qk_ref(qkv, H, n_text, qn_w, qn_b, kn_w, kn_b, cos, sin)
     c = lambda t: t.to(cuda)
-    Qh, Kh, Vt = ops.qk_norm_rope(c(qkv), H, n_text, c(qn_w), c(qn_b), c(kn_w), c(kn_b), 1e-6, c(cos), c(sin), 0.125)
+    Qh, Kh, Vt, kmax2 = ops.qk_norm_rope(c(qkv), H, n_text, c(qn_w), c(qn_b), c(kn_w), c(kn_b), 1e-6, c(cos), c(sin),
+                                         ATTN_Q_SCALE, with_kmax=True)
     torch.cuda.synchronize()
-    _bf16_close(Qh, q * 0.125, "Qh")
+    _bf16_close(Qh, q * ATTN_Q_SCALE, "Qh")
     _bf16_close(Kh, k, "Kh")
     assert torch.equal(Vt.cpu()[..., :S].float(), v.transpose(2, 3))      # transpose only: bit exact
     assert (Vt.cpu()[..., S:] == 0).all()
+    # max ||k||^2 per (batch, head): an fp32 reduction of the pre-rounding values (1e-4 covers the summation order)
+    ref_kmax2 = (k * k).sum(-1).amax(-1).reshape(-1)
+    assert torch.allclose(kmax2.cpu(), ref_kmax2, rtol=1e-4), (kmax2.cpu(), ref_kmax2)
+    # and it bounds the rounded keys the attention kernel will see, with the kernel's 2 % slack
+    assert ((Kh.float().cpu() ** 2).sum(-1).amax(-1).reshape(-1) <= kmax2.cpu() * 1.02).all()
+    # without the optional output the signature is unchanged
+    Qh2, Kh2, Vt2 = ops.qk_norm_rope(c(qkv), H, n_text, c(qn_w), c(qn_b), c(kn_w), c(kn_b), 1e-6, c(cos), c(sin), ATTN_Q_SCALE)
+    torch.cuda.synchronize()
+    assert torch.equal(Qh2, Qh) and torch.equal(Kh2, Kh) and torch.equal(Vt2, Vt)
 
 
-@pytest.mark.parametrize("B,H,S", [(1, 2, 64), (1, 2, 256), (2, 3, 300), (1, 1, 1000), (1, 2, 1541)])
-@pytest.mark.parametrize("flags", [0, 1])
-def test_flash_attention(cuda, hip_lib, B, H, S, flags):
-    from aether_amd import ops
-    g = torch.Generator().manual_seed(S)
-    q = torch.randn(B, H, S, 64, generator=g).to(torch.bfloat16)
-    k = torch.randn(B, H, S, 64, generator=g).to(torch.bfloat16)
-    v = torch.randn(B, H, S, 64, generator=g).to(torch.bfloat16)
+# attention kernel variants: lock-step (narrow / wide store), ping-pong without priority / MFMA-stage priority /
+# soft-max-stage priority
+ATTN_FLAGS = [0, 1, 16 | 1, 16 | 1 | 64, 16 | 128]
+
+
+def _attn_case(B, H, S, seed, q_gain=1.0):
+    from aether_amd._lib import ATTN_Q_SCALE
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(B, H, S, 64, generator=g) * q_gain
+    k = torch.randn(B, H, S, 64, generator=g)
+    v = torch.randn(B, H, S, 64, generator=g)
+    qb = (q * ATTN_Q_SCALE).to(torch.bfloat16)          # softmax scale x log2(e) folded in before the rounding
+    kb, vb = k.to(torch.bfloat16), v.to(torch.bfloat16)
     Spad = (S + 63) // 64 * 64
     vt = torch.zeros(B, H, 64, Spad, dtype=torch.bfloat16)
-    vt[..., :S] = v.transpose(2, 3)
-    ref = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float(), v.float())    # scale 1/8
-    out = ops.flash_attn_fwd((q.float() * 0.125).to(torch.bfloat16).to(cuda), k.to(cuda), vt.to(cuda), flags=flags)
-    torch.cuda.synchronize()
+    vt[..., :S] = vb.transpose(2, 3)
+    # fp32 reference on the SAME rounded operands: softmax over base 2 of qb.kb
+    ref = torch.nn.functional.scaled_dot_product_attention(qb.float(), kb.float(), vb.float(), scale=math.log(2.0))
     ref = ref.transpose(1, 2).reshape(B, S, H * 64)
+    kmax2 = (kb.float() ** 2).sum(-1).amax(-1).reshape(-1).contiguous()
+    return qb, kb, vt, ref, kmax2
+
+
+@pytest.mark.parametrize("B,H,S", [(1, 2, 64), (1, 2, 256), (2, 3, 300), (1, 1, 1000), (1, 2, 1541), (1, 1, 4100)])
+@pytest.mark.parametrize("flags", ATTN_FLAGS)
+@pytest.mark.parametrize("bounded", [False, True])
+def test_flash_attention(cuda, hip_lib, B, H, S, flags, bounded):
+    """bounded=True hands the kernel max||k||^2: with N(0,1) operands ||q'||·||k|| ~ 0.18·8·8·(1.3) < 64, so every wave
+    takes the no-maximum soft-max; bounded=False is the exact online soft-max.  Both must match the fp32 reference."""
+    from aether_amd import ops
+    qb, kb, vt, ref, kmax2 = _attn_case(B, H, S, S)
+    out = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags, kmax2=kmax2.to(cuda) if bounded else None)
+    torch.cuda.synchronize()
     # P is rounded to bf16 before P·V (as every flash kernel does): 1.5e-2 relative L2, 4 bf16 ulps of the scale
-    _bf16_close(out, ref, f"flash S={S}", rel=1.5e-2, max_ulp_frac=4.0)
+    _bf16_close(out, ref, f"flash S={S} flags={flags} bounded={bounded}", rel=1.5e-2, max_ulp_frac=4.0)
 
 
-def test_flash_attention_online_max_jump(cuda, hip_lib):
+@pytest.mark.parametrize("flags", ATTN_FLAGS)
+def test_flash_attention_bound_gate(cuda, hip_lib, flags):
+    """Scores far outside the bounded-score limit (|s| up to ~400 in the log2 domain): exp2(s) without the running
+    maximum would overflow, so the kernel must fall back to the exact soft-max even though a bound was supplied —
+    per wave: rows 0-255 are tame (their waves may take the fast path), rows 256+ are hot."""
+    from aether_amd import ops
+    qb, kb, vt, _, kmax2 = _attn_case(1, 2, 640, 5)
+    qb[:, :, 256:] = (qb[:, :, 256:].float() * 40.0).to(torch.bfloat16)
+    vb = vt[..., :640].transpose(2, 3)
+    ref = torch.nn.functional.scaled_dot_product_attention(qb.float(), kb.float(), vb.float(), scale=math.log(2.0))
+    out = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags, kmax2=kmax2.to(cuda))
+    torch.cuda.synchronize()
+    _bf16_close(out, ref.transpose(1, 2).reshape(1, 640, 128), f"flash bound gate flags={flags}", rel=1.5e-2, max_ulp_frac=4.0)
+    # AETHER_ATTN_EXACT_MAX ignores the bound altogether: bit-identical to running without one
+    a = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags | 32, kmax2=kmax2.to(cuda))
+    b = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags, kmax2=None)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("flags", ATTN_FLAGS)
+def test_flash_attention_online_max_jump(cuda, hip_lib, flags):
     """Force the rescale branch late in the KV sweep: one key far larger than everything before it (guide rule 26)."""
     from aether_amd import ops
+    from aether_amd._lib import ATTN_Q_SCALE
     g = torch.Generator().manual_seed(3)
     B, H, S = 1, 1, 512
     q = torch.randn(B, H, S, 64, generator=g)
@@ -226,10 +277,21 @@ def test_flash_attention_online_max_jump(cuda, hip_lib):
     v = torch.randn(B, H, S, 64, generator=g)
     k[0, 0, 400] = q[0, 0, 7] * 3.0        # row 7's maximum jumps at KV tile 6
     k[0, 0, 130] = q[0, 0, 200] * 2.0
-    qb, kb, vb = [t.to(torch.bfloat16) for t in (q * 0.125, k, v)]
-    ref = torch.nn.functional.scaled_dot_product_attention(qb.float(), kb.float(), vb.float(), scale=1.0)
+    qb, kb, vb = [t.to(torch.bfloat16) for t in (q * ATTN_Q_SCALE, k, v)]
+    ref = torch.nn.functional.scaled_dot_product_attention(qb.float(), kb.float(), vb.float(), scale=math.log(2.0))
     vt = vb.transpose(2, 3).contiguous()
-    for flags in (0, 1):
-        out = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags)
-        torch.cuda.synchronize()
-        _bf16_close(out, ref.transpose(1, 2).reshape(B, S, 64), f"flash max-jump flags={flags}", rel=1.5e-2, max_ulp_frac=4.0)
+    out = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags)
+    torch.cuda.synchronize()
+    _bf16_close(out, ref.transpose(1, 2).reshape(B, S, 64), f"flash max-jump flags={flags}", rel=1.5e-2, max_ulp_frac=4.0)
+
+
+def test_flash_attention_variants_agree_full_size_head(cuda, hip_lib):
+    """One head at the BASELINE sequence length (S = 15 076: 58 full query blocks + a ragged one, 236 KV tiles with a
+    ragged last tile): every kernel variant and both soft-max paths against the fp32 reference."""
+    from aether_amd import ops
+    qb, kb, vt, ref, kmax2 = _attn_case(1, 1, 15076, 77)
+    for flags in ATTN_FLAGS:
+        for bound in (None, kmax2.to(cuda)):
+            out = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags, kmax2=bound)
+            torch.cuda.synchronize()
+            _bf16_close(out, ref, f"flash S=15076 flags={flags} bounded={bound is not None}", rel=1.5e-2, max_ulp_frac=4.0)

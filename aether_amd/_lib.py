@@ -17,10 +17,8 @@ AETHER_EPI_BIAS_GATE_RES = 2
 AETHER_GEMM_WIDE_STORE = 1
 AETHER_GEMM_PINGPONG = 4      # ping-pong main loop (see include/aether_hip.h)
 AETHER_GEMM_PINGPONG2 = 8
-AETHER_ATTN_PINGPONG = 16     # attention: ping-pong kernel
+AETHER_ATTN_PIPELINED = 16    # attention: software-pipelined kernel
 AETHER_ATTN_EXACT_MAX = 32    # attention: ignore the score bound, always run the exact online soft-max
-AETHER_ATTN_PRIO_MFMA = 64    # attention ping-pong: s_setprio 1 in the MFMA stage
-AETHER_ATTN_PRIO_VALU = 128   # attention ping-pong: s_setprio 1 in the soft-max stage
 ATTN_Q_SCALE = 0.125 * 1.4426950408889634   # softmax scale x log2(e): the attention kernel works in the log2 domain
 PROF_CLASSES = ["other", "layernorm", "gemm_qkv", "qk_norm_rope", "attention", "gemm_out", "gemm_ff1", "gemm_ff2"]
 
@@ -49,7 +47,7 @@ SIGNATURES = {
     "aether_unpatchify": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "aether_qk_norm_rope": (_i, [_vp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _f, _fp, _fp, _f, _vp, _vp, _vp, _i, _fp, _vp]),
     "aether_flash_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _fp, _i, _vp]),
-    "aether_conv_gemm_bf16": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _fp, _vp, _i, _i, _vp]),
+    "aether_conv_gemm_bf16": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _fp, _vp, _i, _fp, _sz, _i, _vp]),
     "aether_im2col_first": (_i, [_vp, C.c_long, C.c_long, C.c_long, C.c_long, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "aether_groupnorm_stats": (_i, [_vp, _i, _i, _i, _i, _f, _fp, _fp, _fp, _i, _fp, _fp, _vp]),
     "aether_spatial_cond": (_i, [_vp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _vp]),

@@ -35,6 +35,18 @@ AE_DEV void glds16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Same through a buffer descriptor: address = base(rsrc, wave-uniform SGPRs) + voff (per lane, bytes) + soff (wave-uniform,
+// bytes).  Only `soff` changes from tile to tile, so the per-tile address arithmetic is scalar; bytes at or beyond the
+// descriptor's size are not fetched (no clamping, no fault): the destination then holds zeros or stale data — finite either
+// way once the slot has been written once — and callers mask such elements.
+typedef __amdgpu_buffer_rsrc_t buf_rsrc_t;
+AE_DEV buf_rsrc_t make_buf_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);   // raw buffer, stride 0, 32-bit data format
+}
+AE_DEV void bglds16(buf_rsrc_t rsrc, unsigned voff, unsigned soff, void* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
 template <int N>
 AE_DEV void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

@@ -66,7 +66,7 @@ Plan make_plan(const AetherDitConfig& c, int B, int F, int H, int W) {
     p.off_temb = take((size_t)B * c.time_embed_dim * 4);
     p.off_mod = take((size_t)B * p.Nmod * 4);
     p.off_proj = take((size_t)B * p.Nv * p.Np * 2);
-    p.off_kmax = take((size_t)c.num_layers * B * c.num_heads * 4);
+    p.off_kmax = take((size_t)B * c.num_heads * (p.Spad / 64) * 4);
     p.total = o;
     return p;
 }
@@ -205,11 +205,8 @@ extern "C" int aether_dit_forward(AetherDit* h, const void* hidden, const void* 
 
     // ---- transformer blocks ----------------------------------------------------------------------
     // softmax scale 1/sqrt(64) and log2(e) folded into Q in fp32 before its single rounding to bf16: scores arrive in
-    // the log2 domain.  kmax[i] collects max ||k||^2 per (batch, head) of layer i for the bounded-score soft-max path.
+    // the log2 domain.  kmax receives max ||k||^2 per (batch, head, 64-key tile) of the current layer (bounded-score soft-max path).
     const float q_scale = 0.125f * 1.4426950408889634f;
-    const int BH = B * c.num_heads;
-    if (hipMemsetAsync(kmax, 0, (size_t)L * BH * 4, (hipStream_t)stream) != hipSuccess)
-        return aether_set_error(AETHER_ERR_LAUNCH, "dit_forward: memset failed");
     for (int i = 0; i < L; ++i) {
         const float* m1 = mod + (size_t)i * 12 * D;  // shift, scale, gate, enc_shift, enc_scale, enc_gate
         const float* m2 = m1 + 6 * D;
@@ -218,8 +215,8 @@ extern "C" int aether_dit_forward(AetherDit* h, const void* hidden, const void* 
         AE_RUN(AETHER_PROF_GEMM_QKV, aether_gemm_bf16(xn, D, W_("qkv_w") + (size_t)i * 3 * D * D * 2, D, qkv, 3 * D, M, 3 * D, D,
                                 Wf("qkv_b") + (size_t)i * 3 * D, AETHER_EPI_BIAS, nullptr, 0, nullptr, nullptr, 0, 0, 0, fl, stream));
         AE_RUN(AETHER_PROF_QKROPE, aether_qk_norm_rope(qkv, B, S, c.num_heads, Nt, Wf("qn_w") + i * 64, Wf("qn_b") + i * 64, Wf("kn_w") + i * 64,
-                                   Wf("kn_b") + i * 64, c.qk_norm_eps, rope_cos, rope_sin, q_scale, qh, kh, vt, p.Spad, kmax + (size_t)i * BH, stream));
-        AE_RUN(AETHER_PROF_ATTN, aether_flash_attn_fwd(qh, kh, vt, attn, B, c.num_heads, S, p.Spad, kmax + (size_t)i * BH, fl, stream));
+                                   Wf("kn_b") + i * 64, c.qk_norm_eps, rope_cos, rope_sin, q_scale, qh, kh, vt, p.Spad, kmax, stream));
+        AE_RUN(AETHER_PROF_ATTN, aether_flash_attn_fwd(qh, kh, vt, attn, B, c.num_heads, S, p.Spad, kmax, fl, stream));
         AE_RUN(AETHER_PROF_GEMM_O, aether_gemm_bf16(attn, D, W_("o_w") + (size_t)i * D * D * 2, D, x, D, M, D, D, Wf("o_b") + (size_t)i * D,
                                 AETHER_EPI_BIAS_GATE_RES, x, D, m1 + 2 * D, m1 + 5 * D, p.Nmod, S, Nt, fl, stream));
         AE_RUN(AETHER_PROF_LN, aether_layernorm_modulate(x, D, xn, D, M, D, c.norm_eps, Wf("ln2_w") + (size_t)i * D, Wf("ln2_b") + (size_t)i * D,

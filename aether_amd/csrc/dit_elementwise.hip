@@ -168,14 +168,13 @@ __global__ void unpatchify_kernel(const unsigned short* __restrict__ Y, int ldy,
 }
 
 // ------------------------------------------------------------------------------------------------
-// q/k LayerNorm(64) + RoPE + scale -> head-major Qh/Kh (+ max ||k||^2 per head).  One block per token row; 8 lanes per (part, head).
+// q/k LayerNorm(64) + RoPE + scale -> head-major Qh/Kh.  One block per token row; 8 lanes per (part, head).
 // ------------------------------------------------------------------------------------------------
 struct QkArgs {
     const bf16_t* qkv; int S, H, n_text;
     const float* qn_w; const float* qn_b; const float* kn_w; const float* kn_b; float eps;
     const float* cos_t; const float* sin_t; float q_scale;
     bf16_t* Qh; bf16_t* Kh;
-    float* kmax2;   // [B*H] running max of ||k||^2 (atomic), or null
 };
 
 __global__ __launch_bounds__(256) void qk_norm_rope_kernel(QkArgs p) {
@@ -216,16 +215,6 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(QkArgs p) {
             }
         }
         const float sc = (part == 0) ? p.q_scale : 1.0f;
-        if (p.kmax2 != nullptr && part == 1) {
-            // ||k||^2 of this (token, head): 8 lanes hold 8 elements each.  Non-negative floats order like their bit
-            // patterns, so an unsigned atomicMax works; the (possibly stale) plain read only filters the atomics.
-            float n2 = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) n2 += v[e] * v[e];
-            n2 += __shfl_xor(n2, 1, 64); n2 += __shfl_xor(n2, 2, 64); n2 += __shfl_xor(n2, 4, 64);
-            float* slot = p.kmax2 + (size_t)b * p.H + h;
-            if (sub == 0 && n2 > __builtin_nontemporal_load(slot)) atomicMax((unsigned*)slot, __float_as_uint(n2));
-        }
         uint4 out = make_uint4(pack_bf16x2(v[0] * sc, v[1] * sc), pack_bf16x2(v[2] * sc, v[3] * sc),
                                pack_bf16x2(v[4] * sc, v[5] * sc), pack_bf16x2(v[6] * sc, v[7] * sc));
         bf16_t* dst = (part == 0 ? p.Qh : p.Kh) + (((size_t)b * p.H + h) * p.S + s) * 64 + sub * 8;
@@ -234,13 +223,19 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(QkArgs p) {
 }
 
 // V[b,s,h,:] (inside qkv) -> Vt[b,h,d,s]; 64x64 tile through LDS; pad columns (s >= S) written as zero.
+// The same (64-token, head) blocks also reduce max ||k||^2 over their tile of the freshly written head-major Kh (8 KB,
+// contiguous, still cache resident) into kmax2[(b*H + h)*(Spad/64) + tile]: plain stores, no atomics (236 same-address
+// atomics per head cost ~60 us a layer), on the bf16 values attention will read; attention takes the max over the tiles.
 __global__ __launch_bounds__(256) void v_transpose_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ Vt,
-                                                          int S, int H, int Spad) {
+                                                          int S, int H, int Spad, const unsigned short* __restrict__ Kh,
+                                                          float* __restrict__ kmax2) {
     __shared__ unsigned short tile[64][66];
+    __shared__ float wmax[4];
     const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
     const int s0 = blockIdx.x * 64;
     const int HD = H * 64;
     const int tid = threadIdx.x;
+    float kmx = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int piece = tid + i * 256;  // 512 pieces of 16 B: s_local = piece/8, chunk = piece%8
@@ -249,8 +244,24 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const unsigned short* 
         if (s0 + sl < S) raw = *(const u16x8*)(qkv + ((size_t)b * S + s0 + sl) * 3 * HD + 2 * HD + h * 64 + ch * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) tile[ch * 8 + e][sl] = raw[e];
+        if (kmax2 != nullptr) {   // token s0+sl of Kh: its 64 elements sit in the 8 lanes sharing `sl`
+            float n2 = 0.f;
+            if (s0 + sl < S) {
+                const u16x8 kr = *(const u16x8*)(Kh + ((size_t)bh * S + s0 + sl) * 64 + ch * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float kv = bf16_bits_to_f32(kr[e]); n2 += kv * kv; }
+            }
+            n2 += __shfl_xor(n2, 1, 64); n2 += __shfl_xor(n2, 2, 64); n2 += __shfl_xor(n2, 4, 64);
+            kmx = fmaxf(kmx, n2);
+        }
+    }
+    if (kmax2 != nullptr) {
+        kmx = wave_max(kmx);
+        if ((tid & 63) == 0) wmax[tid >> 6] = kmx;
     }
     __syncthreads();
+    if (kmax2 != nullptr && tid == 0)
+        kmax2[(size_t)bh * gridDim.x + blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int piece = tid + i * 256;  // d = piece/8, s chunk = piece%8
@@ -334,11 +345,11 @@ extern "C" int aether_qk_norm_rope(const void* qkv, int B, int S, int H, int n_t
     if (B <= 0 || S <= 0 || H <= 0 || n_text < 0 || n_text > S) return aether_set_error(AETHER_ERR_SHAPE, "qk_norm_rope: bad shape");
     if (n_text < S && (!cos_t || !sin_t)) return aether_set_error(AETHER_ERR_ARG, "qk_norm_rope: rope tables required");
     if (Spad % 64 != 0 || Spad < S) return aether_set_error(AETHER_ERR_SHAPE, "qk_norm_rope: Spad must be roundup(S,64)");
-    QkArgs p{(const bf16_t*)qkv, S, H, n_text, qn_w, qn_b, kn_w, kn_b, eps, cos_t, sin_t, q_scale, (bf16_t*)Qh, (bf16_t*)Kh, kmax2};
+    QkArgs p{(const bf16_t*)qkv, S, H, n_text, qn_w, qn_b, kn_w, kn_b, eps, cos_t, sin_t, q_scale, (bf16_t*)Qh, (bf16_t*)Kh};
     hipLaunchKernelGGL(qk_norm_rope_kernel, dim3(B * S), dim3(256), 0, AE_STREAM, p);
     int rc = aether_check_launch("qk_norm_rope");
     if (rc) return rc;
     hipLaunchKernelGGL(v_transpose_kernel, dim3(Spad / 64, B * H), dim3(256), 0, AE_STREAM, (const unsigned short*)qkv,
-                       (unsigned short*)Vt, S, H, Spad);
+                       (unsigned short*)Vt, S, H, Spad, (const unsigned short*)Kh, kmax2);
     return aether_check_launch("v_transpose");
 }

@@ -17,7 +17,7 @@
 //     fragment is a plain 16-byte row read.
 //   * bounded-score fast path: at head_dim 64 the kernel is VALU-issue bound (≈5 VALU slots per score against
 //     16 MFMAs per 2048 scores), so the biggest lever is fewer VALU ops per score.  q and k are LayerNorm outputs,
-//     so |q·k| ≤ ‖q‖·max‖k‖ (Cauchy–Schwarz); aether_qk_norm_rope emits max‖k‖² per (batch, head).  When that bound
+//     so |q·k| ≤ ‖q‖·max‖k‖ (Cauchy–Schwarz); aether_qk_norm_rope emits max‖k‖² per (batch, head, 64-key tile).  When that bound
 //     is ≤ 64 for every row of a wave, exp2(s) can neither overflow nor underflow in fp32/bf16 and soft-max is
 //     shift invariant, so the wave runs p = exp2(s) with NO running maximum, NO subtraction and NO rescale
 //     (1 v_exp + 1 v_add + ½ v_cvt_pk per score).  Otherwise (or when no bound is supplied) it runs the exact
@@ -32,6 +32,7 @@
 //   LDS-DMA of tile j+4) — the matrix pipe of every SIMD always has one wave feeding it while its partner does
 //   the soft-max.  4-deep K/V ring in LDS (64 KiB), DMA waits are counted (vmcnt(2)), never drained in the loop.
 #include <type_traits>
+#include <utility>
 #include "common.hpp"
 #include "../../include/aether_hip.h"
 
@@ -45,7 +46,7 @@ constexpr float FA_BOUND_SLACK = 1.02f;        // covers the bf16 rounding of k 
 
 struct FlashArgs {
     const bf16_t* Q; const bf16_t* K; const bf16_t* Vt; bf16_t* O;
-    const float* kmax2;   // [B*H] upper bound of ‖k‖² per (batch, head), or null
+    const float* kmax2;   // [B*H][Spad/64] upper bound of ‖k‖² per (batch, head, 64-key tile), or null
     int H, S, Spad, nqb, nwg;
 };
 
@@ -124,15 +125,17 @@ AE_DEV void fa_softmax(const f32x16 (&sc)[2], bf16x8 (&pf)[2][2], f32x16 (&o)[2]
 }
 
 // per-wave decision: every row of this wave has (‖q‖·max‖k‖)² within the bounded-score limit
-AE_DEV bool fa_fast_ok(const bf16x8 (&qf)[4], const float* kmax2, int bh) {
+AE_DEV bool fa_fast_ok(const bf16x8 (&qf)[4], const float* kmax2, int bh, int ntiles) {
     if (kmax2 == nullptr) return false;
+    float km = 0.f;
+    for (int i = threadIdx.x & 63; i < ntiles; i += 64) km = fmaxf(km, kmax2[(size_t)bh * ntiles + i]);
+    km = wave_max(km);
     float qn2 = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const float q = (float)qf[ks][e]; qn2 += q * q; }
     qn2 += __shfl_xor(qn2, 32, 64);
-    const float km = kmax2[bh];
     return __all(qn2 * km * FA_BOUND_SLACK <= FA_FAST_BOUND2) != 0;
 }
 
@@ -195,14 +198,19 @@ void flash_attn_fwd_kernel(FlashArgs p) {
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(Qg + (size_t)qrow_c * FA_D + 16 * ks + 8 * hi);
 
     // ---- staging (one 16-byte piece of K and one of Vᵀ per thread per KV tile) ---------------------
+    // buffer-descriptor DMA: the per-lane offsets are loop invariant, the tile advance is a scalar offset; K rows >= S
+    // of the ragged last tile are out of range of the descriptor (not fetched; their scores are masked below)
     const int srow = tid >> 3;                          // K: key row in tile; Vᵀ: d row
     const int schunk = (tid & 7) ^ ((srow >> 1) & 7);   // logical chunk fetched into physical chunk tid&7
-    char* const lds_stage = smem + L.wave * 1024;
-    const bf16_t* const vsrc = Vg + (size_t)srow * p.Spad + schunk * 8;
+    const int wave_s = __builtin_amdgcn_readfirstlane(L.wave);
+    char* const lds_stage = smem + wave_s * 1024;
+    const buf_rsrc_t k_rsrc = make_buf_rsrc(Kg, (unsigned)S * FA_D * 2);
+    const buf_rsrc_t v_rsrc = make_buf_rsrc(Vg, (unsigned)p.Spad * FA_D * 2);
+    const unsigned k_voff = srow * (FA_D * 2) + schunk * 16;
+    const unsigned v_voff = (unsigned)srow * p.Spad * 2 + schunk * 16;
     auto stage = [&](int j, int buf) {
-        const int krow = min(j * FA_KVBLK + srow, S - 1);
-        glds16(Kg + (size_t)krow * FA_D + schunk * 8, lds_stage + buf * FA_BUF);
-        glds16(vsrc + j * FA_KVBLK, lds_stage + buf * FA_BUF + FA_TILE);
+        bglds16(k_rsrc, k_voff, j * (FA_KVBLK * FA_D * 2), lds_stage + buf * FA_BUF);
+        bglds16(v_rsrc, v_voff, j * (FA_KVBLK * 2), lds_stage + buf * FA_BUF + FA_TILE);
     };
 
     f32x16 o[2];
@@ -214,7 +222,7 @@ void flash_attn_fwd_kernel(FlashArgs p) {
     const int nkv = (S + FA_KVBLK - 1) / FA_KVBLK;
     const bool ragged = (S & (FA_KVBLK - 1)) != 0;
     stage(0, 0);
-    const bool fast = fa_fast_ok(qf, p.kmax2, bh);
+    const bool fast = fa_fast_ok(qf, p.kmax2, bh, p.Spad / FA_KVBLK);
     drain_and_barrier();
 
     auto sweep = [&](auto fast_tag) {
@@ -260,17 +268,35 @@ void flash_attn_fwd_kernel(FlashArgs p) {
 }
 
 // =================================================================================================================
-// ping-pong kernel: one workgroup per CU, waves w and w+4 (same SIMD) alternate MFMA stage / soft-max stage
+// software-pipelined kernel: one workgroup per CU (two waves per SIMD), soft-max of tile j interleaved, inside each
+// wave, with the MFMAs of P·V(j-1) and K(j+1)·Qᵀ
 // =================================================================================================================
-constexpr int FA_NB = 4;  // K/V ring depth
+// Measured on MI355X (tools/probes/valu_probe.hip, profiles/r01_valu_probe.jsonl): VALU work issued by the SAME wave
+// between its MFMAs hides under them (16 MFMA + 32 v_exp + 32 v_add + 16 v_cvt_pk interleaved: 680 cycles against 512
+// for the bare MFMAs), whereas the same VALU work issued by the OTHER wave of the SIMD serialises with the MFMAs
+// (1027 cycles) — so the overlap has to be built inside each wave: the loop body carries two score tiles and two P
+// fragments (sc/pf of tile j being soft-maxed, sc of tile j+1 being produced, pf of tile j-1 being consumed).
+constexpr int FA_NB = 4;  // K/V ring depth (tile t lives in slot t & 3)
 
-// PRIO: 0 no priority, 1 the MFMA stage runs at s_setprio 1, 2 the soft-max stage runs at s_setprio 1
-template <bool WIDE_STORE, int PRIO>
-__global__ __launch_bounds__(512) void flash_attn_pp_kernel(FlashArgs p) {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int I> using ic = std::integral_constant<int, I>;
+template <class F, int... Is> AE_DEV void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(ic<Is>{}), ...); }
+template <int N, class F> AE_DEV void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// Timing ablations of this kernel (profiles/r01_attn_swp_ablation.json, shader cycles per KV tile for the two waves of
+// a SIMD): full 1721, without the LDS-DMA 1623, without the soft-max VALU 1203 (16 MFMAs = 2 x 512); fragment reads 2 / 4 /
+// 6 / 8 MFMAs ahead: 1720 / 1671 / 1703 / 1760 (profiles/r01_attn_swp_prefetch.json).
+constexpr int FA_AHEAD = 4;   // fragment reads are issued this many MFMAs ahead of their use
+
+template <bool WIDE_STORE>
+__global__ __launch_bounds__(512) void flash_attn_swp_kernel(FlashArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[FA_NB * FA_BUF];
     const FaLane L = fa_lane_setup();
     const int tid = threadIdx.x, hi = L.hi;
-    const int grp = __builtin_amdgcn_readfirstlane(L.wave >> 2);   // waves 4-7 share SIMDs with waves 0-3
+    const int wave_s = __builtin_amdgcn_readfirstlane(L.wave);
 
     const int wgid = xcd_remap(blockIdx.x, p.nwg);
     const int bh = wgid / p.nqb;
@@ -289,106 +315,161 @@ __global__ __launch_bounds__(512) void flash_attn_pp_kernel(FlashArgs p) {
 
     const int srow = tid >> 3;
     const int schunk = (tid & 7) ^ ((srow >> 1) & 7);
-    char* const lds_stage = smem + L.wave * 1024;
-    const bf16_t* const vsrc = Vg + (size_t)srow * p.Spad + schunk * 8;
+    char* const lds_stage = smem + wave_s * 1024;
     const int nkv = (S + FA_KVBLK - 1) / FA_KVBLK;
-    // tile j -> ring slot j & 3.  Tiles past the end re-fetch the last tile into a slot nobody reads any more: the main
-    // loop stays branch free (uniform vmcnt accounting) at the price of <= 3 redundant tile loads per workgroup.
-    auto stage = [&](int j) {
-        const int buf = j & (FA_NB - 1);
-        const int jc = min(j, nkv - 1);
-        const int krow = min(jc * FA_KVBLK + srow, S - 1);
-        glds16(Kg + (size_t)krow * FA_D + schunk * 8, lds_stage + buf * FA_BUF);
-        glds16(vsrc + jc * FA_KVBLK, lds_stage + buf * FA_BUF + FA_TILE);
-    };
+    // buffer-descriptor DMA (scalar tile advance, no per-tile VALU).  Tiles past the end re-fetch the last tile (finite
+    // data) into a slot nobody needs any more: the loop stays branch free with uniform vmcnt accounting; the scores of
+    // such a tile — like those of the keys >= S of the ragged last tile, which the K descriptor does not cover — are
+    // masked to -inf, so they contribute exactly 0.
+    const buf_rsrc_t k_rsrc = make_buf_rsrc(Kg, (unsigned)S * FA_D * 2);
+    const buf_rsrc_t v_rsrc = make_buf_rsrc(Vg, (unsigned)p.Spad * FA_D * 2);
+    const unsigned k_voff = srow * (FA_D * 2) + schunk * 16;
+    const unsigned v_voff = (unsigned)srow * p.Spad * 2 + schunk * 16;
+    auto stage_k = [&](int j, int slot) { bglds16(k_rsrc, k_voff, min(j, nkv - 1) * (FA_KVBLK * FA_D * 2), lds_stage + slot * FA_BUF); };
+    auto stage_v = [&](int j, int slot) { bglds16(v_rsrc, v_voff, min(j, nkv - 1) * (FA_KVBLK * 2), lds_stage + slot * FA_BUF + FA_TILE); };
 
     f32x16 o[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
 
-    const bool ragged = (S & (FA_KVBLK - 1)) != 0;
-#pragma unroll
-    for (int t = 0; t < 3; ++t) stage(t);
-    const bool fast = fa_fast_ok(qf, p.kmax2, bh);
+    stage_k(0, 0); stage_v(0, 0); stage_k(1, 1); stage_v(1, 1); stage_k(2, 2);
+    const bool fast = fa_fast_ok(qf, p.kmax2, bh, p.Spad / FA_KVBLK);
     drain_and_barrier();
-
-    auto slot_end = [&]() {
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    };
 
     auto sweep = [&](auto fast_tag) {
         constexpr bool FAST = decltype(fast_tag)::value;
-        bf16x8 kf[2][4], vf[2][2][2], pf[2][2];
-        f32x16 sc[2];
-        auto load_k = [&](int j) {
-            const char* base = smem + (j & (FA_NB - 1)) * FA_BUF;
+        f32x16 sc_a[2], sc_b[2];
+        u32x4 pf_a[2][2], pf_b[2][2];   // P fragments as packed bf16 pairs
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) kf[t][ks] = *(const bf16x8*)(base + t * 4096 + L.koff[ks]);
-        };
-        auto load_v = [&](int j) {
-            const char* base = smem + (j & (FA_NB - 1)) * FA_BUF;
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
+                for (int e = 0; e < 4; ++e) pf_b[t][s][e] = 0u;
+        // prologue: scores of tile 0
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sc_a[t][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                sc_a[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(smem + t * 4096 + L.koff[ks]), qf[ks], sc_a[t], 0, 0, 0);
+        }
+        f32x2 lsum[2] = {{0.f, 0.f}, {0.f, 0.f}};   // FAST: packed partial row sums (v_pk_fma_f32 with 1.0)
+        f32x2 ones = {1.f, 1.f};
+        asm volatile("" : "+v"(ones));   // opaque: keeps v_pk_fma_f32 (6 cycles / wave) from being folded to v_pk_add_f32 (11.6)
+
+        // One iteration = tile j (ring slots are compile-time: the loop is unrolled by 4):
+        //   MFMA  o += Vᵀ(j-1)·pf_prev (8) then sc_nxt = K(j+1)·Qᵀ (8);   VALU  pf_cur = softmax(sc_cur)
+        // LDS ring at iteration j: Vᵀ(j-1), [Vᵀ(j)], K(j+1) are read/live; K(j+3) -> K half of slot (j-1)&3 (last read at
+        // iteration j-2) and Vᵀ(j+2) -> V half of slot (j-2)&3 (last read at iteration j-1) are issued now and waited for
+        // one iteration later (vmcnt(2)): K lands two iterations ahead of its use, Vᵀ three.
+        auto iter = [&](int j, auto slot_tag, f32x16 (&sc_cur)[2], f32x16 (&sc_nxt)[2], u32x4 (&pf_prev)[2][2], u32x4 (&pf_cur)[2][2]) {
+            constexpr int SL = decltype(slot_tag)::value;          // j & 3
+            constexpr int KSLOT = (SL + 1) & 3, VSLOT = (SL + 3) & 3;   // slots of tile j+1 and tile j-1
+            if constexpr (!FAST) {
+                stage_k(j + 3, VSLOT);                              // (j+3)&3 == (j-1)&3
+                stage_v(j + 2, (SL + 2) & 3);
+            }
+            if ((j + 1) * FA_KVBLK > S) fa_mask_tail(sc_cur, j, hi, S);
+            // j = 0: pf_prev is 0 and slot 3 is still uninitialised LDS (0 x NaN): read tile 0's Vᵀ instead
+            const char* kbase = smem + KSLOT * FA_BUF;
+            const char* vbase = smem + ((SL == 0 && j == 0) ? 0 : VSLOT) * FA_BUF;
+            // fragment i of the 16 MFMAs: 0-7 Vᵀ(dt = i&1, t = i>>2, s = (i>>1)&1), 8-15 K(t = i&1, ks = (i-8)>>1)
+            auto frag = [&](auto I) -> bf16x8 {
+                constexpr int i = decltype(I)::value;
+                if constexpr (i < 8) return *(const bf16x8*)(vbase + (i & 1) * 4096 + L.voff[i >> 2][(i >> 1) & 1]);
+                else return *(const bf16x8*)(kbase + (i & 1) * 4096 + L.koff[(i - 8) >> 1]);
+            };
+            if constexpr (FAST) {
+                // hand interleave, pinned by sched_barrier: per MFMA one fragment read (two ahead) and the soft-max of two
+                // scores (2 v_exp, 1 v_pk_fma row sum, 1 v_cvt_pk)
+                bf16x8 fr[16];
+                static_for<FA_AHEAD>([&](auto I) { fr[decltype(I)::value] = frag(I); });
+                static_for<16>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    if constexpr (i + FA_AHEAD < 16) fr[i + FA_AHEAD] = frag(ic<i + FA_AHEAD>{});
+                    // the two DMA pieces of this iteration go out in the shadow of the MFMAs, not at the barrier
+                    if constexpr (i == 2) stage_k(j + 3, VSLOT);            // (j+3)&3 == (j-1)&3
+                    if constexpr (i == 9) stage_v(j + 2, (SL + 2) & 3);
+                    if constexpr (i < 8) {
+                        o[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], __builtin_bit_cast(bf16x8, pf_prev[i >> 2][(i >> 1) & 1]), o[i & 1], 0, 0, 0);
+                    } else {
+                        constexpr int t = i & 1, ks = (i - 8) >> 1;
+                        if constexpr (ks == 0) {
+                            f32x16 z;
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) z[e] = 0.f;
+                            sc_nxt[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], qf[ks], z, 0, 0, 0);
+                        } else {
+                            sc_nxt[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], qf[ks], sc_nxt[t], 0, 0, 0);
+                        }
+                    }
+                    // scores 2i, 2i+1 of this lane: tile t = i>>3, slab s = (i>>2)&1, elements e = 2(i&3), +1
+                    constexpr int t = i >> 3, s = (i >> 2) & 1, e = 2 * (i & 3);
+                    f32x2 pp;
+                    pp[0] = __builtin_amdgcn_exp2f(sc_cur[t][8 * s + e]);
+                    pp[1] = __builtin_amdgcn_exp2f(sc_cur[t][8 * s + e + 1]);
+                    lsum[i & 1] = __builtin_elementwise_fma(pp, ones, lsum[i & 1]);
+                    unsigned w = pack_bf16x2(pp[0], pp[1]);
+                    // the results are first USED one iteration later: without these anchors the compiler sinks the whole
+                    // soft-max past the barrier, next to its use, and the interleave is gone
+                    asm volatile("" : "+v"(w), "+v"(lsum[i & 1]));
+                    pf_cur[t][s][e / 2] = w;
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            } else {
+                // exact online soft-max: compiler-scheduled (the MFMAs below do not depend on this tile's soft-max)
+                static_for<16>([&](auto I) {
+                    constexpr int i = decltype(I)::value;
+                    const bf16x8 f = frag(I);
+                    if constexpr (i < 8) {
+                        o[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, __builtin_bit_cast(bf16x8, pf_prev[i >> 2][(i >> 1) & 1]), o[i & 1], 0, 0, 0);
+                    } else {
+                        constexpr int t = i & 1, ks = (i - 8) >> 1;
+                        if constexpr (ks == 0) {
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) sc_nxt[t][e] = 0.f;
+                        }
+                        sc_nxt[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, qf[ks], sc_nxt[t], 0, 0, 0);
+                    }
+                });
+                bf16x8 pfx[2][2];
+                fa_softmax<false>(sc_cur, pfx, o, m_run, l_run);
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) vf[dt][t][s] = *(const bf16x8*)(base + dt * 4096 + L.voff[t][s]);
+                    for (int s = 0; s < 2; ++s) {
+                        pf_cur[t][s] = __builtin_bit_cast(u32x4, pfx[t][s]);
+                        asm volatile("" : "+v"(pf_cur[t][s]));   // keep the soft-max in this iteration (see above)
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            block_barrier();
+            __builtin_amdgcn_sched_barrier(0);
         };
-        auto qk = [&]() {   // sc = K(j+1)·Qᵀ : 8 MFMAs alternating the two accumulators
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { sc[0][i] = 0.f; sc[1][i] = 0.f; }
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) sc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t][ks], qf[ks], sc[t], 0, 0, 0);
-        };
-        auto pv = [&]() {   // o += Vᵀ(j)·Pᵀ(j) : 8 MFMAs alternating the two accumulators
+
+        const int n4 = (nkv + 3) & ~3;   // the tile count is padded to a multiple of 4 with fully masked tiles
+        for (int j = 0; j < n4; j += 4) {
+            iter(j, ic<0>{}, sc_a, sc_b, pf_b, pf_a);
+            iter(j + 1, ic<1>{}, sc_b, sc_a, pf_a, pf_b);
+            iter(j + 2, ic<2>{}, sc_a, sc_b, pf_b, pf_a);
+            iter(j + 3, ic<3>{}, sc_b, sc_a, pf_a, pf_b);
+        }
+        // epilogue: P·V of the last tile (pf_b), Vᵀ(n4-1) lives in slot 3
+        {
+            const char* vbase = smem + 3 * FA_BUF;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][t][s], pf[t][s], o[dt], 0, 0, 0);
-        };
-
-        // Slot schedule (B = s_barrier).  group 0:  P0 B (V0 B M0 B) (V1 B M1 B) ... B      P0 = K(0)·Qᵀ
-        //                                  group 1:  B P0 B (V0 B M0 B) ...                   (one slot behind)
-        //   Vj: reads Vᵀ(j), K(j+1) fragments; issues the DMA of tile j+3; soft-max of tile j; waits for tile j+2
-        //   Mj: P·V of tile j and K(j+1)·Qᵀ, registers only (past the last tile the K·Qᵀ result is simply unused)
-        // Ring safety: slot (j+3)&3 last held tile j-1, whose last read (Vᵀ(j-1)) was in V(j-1) of either group, two or
-        // more barriers earlier; tile j+2 was issued in V(j-1) and is waited for (vmcnt(2)) before the barrier ending
-        // Vj, so every wave's piece has landed before any wave reads K(j+2) in V(j+1) / Vᵀ(j+2) in V(j+2).
-        load_k(0);
-        wait_lgkmcnt0();
-        if (grp) slot_end();
-        if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
-        qk();
-        if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
-        slot_end();
-        for (int j = 0; j < nkv; ++j) {
-            if (PRIO == 2) __builtin_amdgcn_s_setprio(1);
-            load_v(j);
-            load_k(j + 1);
-            stage(j + 3);
-            if (j == nkv - 1 && ragged) fa_mask_tail(sc, j, hi, S);
-            fa_softmax<FAST>(sc, pf, o, m_run, l_run);
-            __builtin_amdgcn_sched_barrier(0);   // the soft-max VALU stays in THIS stage, ahead of the wait
-            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-            if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
-            slot_end();
-            if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
-            pv();
-            qk();
-            if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
-            slot_end();
+                    for (int dt = 0; dt < 2; ++dt)
+                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(vbase + dt * 4096 + L.voff[t][s]), __builtin_bit_cast(bf16x8, pf_b[t][s]), o[dt], 0, 0, 0);
         }
-        if (!grp) slot_end();
+        if constexpr (FAST) l_run += (lsum[0][0] + lsum[0][1]) + (lsum[1][0] + lsum[1][1]);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant tail DMA must not outlive the workgroup's LDS
     };
     if (fast) sweep(std::true_type{});
@@ -417,12 +498,9 @@ extern "C" int aether_flash_attn_fwd(const void* Qh, const void* Kh, const void*
     hipStream_t s = (hipStream_t)stream;
     const bool wide = (flags & AETHER_GEMM_WIDE_STORE) != 0;
     dim3 grid(p.nwg), block(512);
-    if (flags & AETHER_ATTN_PINGPONG) {
-        const int prio = (flags >> 6) & 3;
-#define FA_PP(W, P) hipLaunchKernelGGL((flash_attn_pp_kernel<W, P>), grid, block, 0, s, p)
-        if (wide) { if (prio == 1) FA_PP(true, 1); else if (prio == 2) FA_PP(true, 2); else FA_PP(true, 0); }
-        else      { if (prio == 1) FA_PP(false, 1); else if (prio == 2) FA_PP(false, 2); else FA_PP(false, 0); }
-#undef FA_PP
+    if (flags & AETHER_ATTN_PIPELINED) {
+        if (wide) hipLaunchKernelGGL((flash_attn_swp_kernel<true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((flash_attn_swp_kernel<false>), grid, block, 0, s, p);
     } else if (wide) {
         hipLaunchKernelGGL((flash_attn_fwd_kernel<true>), grid, block, 0, s, p);
     } else {

@@ -42,6 +42,10 @@ struct GemmArgs {
     int stride_hw;              // spatial stride (1, or 2 for the down-sampling conv2d)
     int stagger;                // main loop: 0 = one barrier per K tile (all waves in lock-step); 1 = ping-pong, one k-step per
                                 // slot; 2 = ping-pong, two k-steps per slot
+    // split-K (launches with too few output tiles to fill 256 CUs: the deep, low-resolution VAE layers with K = 27*512):
+    int ksplit;                 // 1 = off; otherwise grid = tiles * ksplit and workgroup (tile, slice) accumulates K tiles
+                                // [slice*nk/ksplit, (slice+1)*nk/ksplit) and stores its raw fp32 tile to part[slice][M][N]
+    float* part;                // fp32 [ksplit][M][N]; summed in slice order (deterministic) by splitk_finalize_kernel
 };
 
 constexpr int GEMM_BK = 64;
@@ -67,7 +71,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
 
     // ---- tile assignment: XCD-aware remap, then groups of GEMM_GROUP_M row tiles x all column tiles ------------
     const int nwg = p.tiles_m * p.tiles_n;
-    const int wgid = xcd_remap(blockIdx.x, nwg);
+    const int kslice = (p.ksplit > 1) ? (int)blockIdx.x / nwg : 0;
+    const int wgid = xcd_remap((int)blockIdx.x - kslice * nwg, nwg);
     const int per_group = GEMM_GROUP_M * p.tiles_n;
     const int group = wgid / per_group;
     const int first_m = group * GEMM_GROUP_M;
@@ -102,7 +107,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
     char* const lds_stage = smem + wave * 1024;
     const bool w_active = (BN >= 64) || (srow < BN);   // BN = 32: only half of the threads carry weight rows
 
+    const int nk_all = p.K / GEMM_BK;
+    const int k_first = (p.ksplit > 1) ? (int)((long)kslice * nk_all / p.ksplit) : 0;     // this workgroup's K tiles:
+    const int nk = ((p.ksplit > 1) ? (int)((long)(kslice + 1) * nk_all / p.ksplit) : nk_all) - k_first;   // [k_first, k_first + nk)
     auto stage = [&](int kt, int buf) {
+        kt += k_first;
         const bf16_t* Ak = p.A + (GATHER ? p.tap_off[kt] : kt * GEMM_BK);
         const bf16_t* Wk = p.W + kt * GEMM_BK;
         char* dst = lds_stage + buf * BUF_BYTES;
@@ -131,7 +140,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
 
-    const int nk = p.K / GEMM_BK;
     stage(0, 0);
     drain_and_barrier();
 
@@ -159,6 +167,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
             // DMA pieces of tile kt split in NPART parts, one per early compute slot
             constexpr int NPART = (KSPS == 1) ? 3 : 1;
             auto stage_part = [&](int kt, int buf, int part) {
+                kt += k_first;
                 const bf16_t* Ak = p.A + (GATHER ? p.tap_off[kt] : kt * GEMM_BK);
                 const bf16_t* Wk = p.W + kt * GEMM_BK;
                 char* dst = lds_stage + buf * BUF_BYTES;
@@ -251,6 +260,25 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
 
     // ---- epilogue ------------------------------------------------------------------------------------------------
     // acc[mt][nt][r] = C[m][n], m = m0 + (wm*MT + mt)*32 + l32,  n = n0 + (wn*NT + nt)*32 + 8*(r>>2) + 4*hi + (r&3)
+    if (p.ksplit > 1) {   // split-K: raw fp32 partial tile; bias / residual / rounding happen in splitk_finalize_kernel
+        float* part = p.part + (size_t)kslice * p.M * p.N;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m0 + (wm * MT + mt) * 32 + l32;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int nbase = n0 + (wn * NT + nt) * 32;
+                if (nbase >= p.N) continue;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+                    *(f32x4*)(part + (size_t)m * p.N + nbase + 8 * g + 4 * hi) = v;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int m = m0 + (wm * MT + mt) * 32 + l32;

@@ -115,6 +115,39 @@ __global__ __launch_bounds__(256) void resample_pad_kernel(ResampleArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// split-K finalize: C[m][n] = bf16( sum_s part[s][m][n] (slice order: deterministic) + bias[n] + R[m][n] )
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __restrict__ part, int ksplit, int M, int N,
+                                                              const float* __restrict__ bias, const unsigned short* __restrict__ R,
+                                                              int ldr, unsigned short* __restrict__ C, int ldc) {
+    const int oct_per_row = N >> 3;
+    const long total = (long)M * oct_per_row;
+    const size_t slice = (size_t)M * N;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int oct = idx % oct_per_row;
+        const long m = idx / oct_per_row;
+        const float* src = part + (size_t)m * N + oct * 8;
+        f32x4 a0 = *(const f32x4*)src, a1 = *(const f32x4*)(src + 4);
+        for (int s = 1; s < ksplit; ++s) {
+            a0 += *(const f32x4*)(src + s * slice);
+            a1 += *(const f32x4*)(src + s * slice + 4);
+        }
+        float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        if (bias != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bias[oct * 8 + e];
+        }
+        if (R != nullptr) {
+            const u16x8 r = *(const u16x8*)(R + (size_t)m * ldr + oct * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bf16_bits_to_f32(r[e]);
+        }
+        *(uint4*)(C + (size_t)m * ldc + oct * 8) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                                              pack_bf16x2(v[6], v[7]));
+    }
+}
+
 }  // namespace aether
 
 using namespace aether;
@@ -127,7 +160,8 @@ static int grid_for(long total_threads) {
 
 extern "C" int aether_conv_gemm_bf16(const void* X, int NB, int iT, int iH, int iW, int iC, int oT, int oH, int oW, int stride_hw,
                                      const int* tap_off, int n_taps, const void* W, int Cout, void* C, int ldc,
-                                     const float* bias, const void* R, int ldr, int flags, void* stream) {
+                                     const float* bias, const void* R, int ldr, float* splitk_ws, size_t splitk_ws_bytes, int flags,
+                                     void* stream) {
     const int K = n_taps * 64;
     const long Ml = (long)NB * oT * oH * oW;
     if (Ml <= 0 || Ml >= (1l << 31)) return aether_set_error(AETHER_ERR_SHAPE, "conv_gemm: bad output volume");
@@ -138,6 +172,7 @@ extern "C" int aether_conv_gemm_bf16(const void* X, int NB, int iT, int iH, int 
     if (iC % 64 != 0) return aether_set_error(AETHER_ERR_SHAPE, "conv_gemm: input channels must be a multiple of 64");
     if (stride_hw != 1 && stride_hw != 2) return aether_set_error(AETHER_ERR_SHAPE, "conv_gemm: stride must be 1 or 2");
     if ((size_t)NB * iT * iH * iW * iC >= (1ull << 32)) return aether_set_error(AETHER_ERR_SHAPE, "conv_gemm: input volume exceeds 32-bit element offsets");
+    if (splitk_ws != nullptr && (((uintptr_t)splitk_ws) & 15)) return aether_set_error(AETHER_ERR_ALIGN, "conv_gemm: split-K workspace must be 16-byte aligned");
     GemmArgs p = {};
     p.A = (const bf16_t*)X; p.lda = 0;
     p.W = (const bf16_t*)W; p.ldw = K;
@@ -151,10 +186,23 @@ extern "C" int aether_conv_gemm_bf16(const void* X, int NB, int iT, int iH, int 
     const bool wide = (flags & AETHER_GEMM_WIDE_STORE) != 0;
     p.stagger = (flags >> 2) & 3;
     dim3 block(512);
+    // split-K when the output tiles cannot fill the chip (one 128-KiB-LDS workgroup per CU, 256 CUs): the deep layers have
+    // K = 27*512 = 216 K tiles walked serially by a handful of workgroups otherwise.  Slices >= 4 K tiles, total <= 256 WGs.
+    auto pick_ksplit = [&](int tiles) {
+        if (splitk_ws == nullptr || tiles > 128) return 1;
+        int ks = 256 / tiles;
+        ks = ks < n_taps / 4 ? ks : n_taps / 4;
+        const size_t per_slice = (size_t)M * Cout * sizeof(float);
+        if (per_slice == 0) return 1;
+        const size_t fit = splitk_ws_bytes / per_slice;
+        if ((size_t)ks > fit) ks = (int)fit;
+        return ks < 2 ? 1 : ks;
+    };
 #define LAUNCH_CFG(WM_, WN_, MT_, NT_, BM_, BN_)                                                                                   \
     do {                                                                                                                            \
         p.tiles_m = (M + BM_ - 1) / BM_; p.tiles_n = (Cout + BN_ - 1) / BN_;                                                         \
-        dim3 grid(p.tiles_m * p.tiles_n);                                                                                          \
+        p.ksplit = pick_ksplit(p.tiles_m * p.tiles_n); p.part = splitk_ws;                                                           \
+        dim3 grid(p.tiles_m * p.tiles_n * p.ksplit);                                                                               \
         if (R) { if (wide) hipLaunchKernelGGL((gemm_bf16_kernel<WM_, WN_, MT_, NT_, EPI_BIAS_GATE_RES, true, true>), grid, block, 0, AE_STREAM, p); \
                  else hipLaunchKernelGGL((gemm_bf16_kernel<WM_, WN_, MT_, NT_, EPI_BIAS_GATE_RES, false, true>), grid, block, 0, AE_STREAM, p); }    \
         else { if (wide) hipLaunchKernelGGL((gemm_bf16_kernel<WM_, WN_, MT_, NT_, EPI_BIAS, true, true>), grid, block, 0, AE_STREAM, p);            \
@@ -164,7 +212,11 @@ extern "C" int aether_conv_gemm_bf16(const void* X, int NB, int iT, int iH, int 
     else if (Cout % 128 == 0) LAUNCH_CFG(4, 2, 4, 2, 512, 128);
     else LAUNCH_CFG(8, 1, 2, 1, 512, 32);
 #undef LAUNCH_CFG
-    return aether_check_launch("conv_gemm_bf16");
+    rc = aether_check_launch("conv_gemm_bf16");
+    if (rc || p.ksplit <= 1) return rc;
+    hipLaunchKernelGGL(splitk_finalize_kernel, dim3(grid_for((long)M * (Cout / 8))), dim3(256), 0, AE_STREAM, (const float*)splitk_ws, p.ksplit, M,
+                       Cout, bias, (const unsigned short*)R, ldr, (unsigned short*)C, ldc);
+    return aether_check_launch("splitk_finalize");
 }
 
 extern "C" int aether_im2col_first(const void* x, long sC, long sT, long sH, long sW, int Cin, int t0, int first_chunk, int y0,

@@ -96,7 +96,7 @@ def unpatchify(Y, B, F, Cout, H, W, p):
 
 
 def qk_norm_rope(qkv, H, n_text, qn_w, qn_b, kn_w, kn_b, eps, cos, sin, q_scale, with_kmax=False):
-    """qkv bf16 [B,S,3*H*64] -> (Qh [B,H,S,64], Kh [B,H,S,64], Vt [B,H,64,Spad]) (+ kmax2 fp32 [B*H] = max ||k||^2)."""
+    """qkv bf16 [B,S,3*H*64] -> (Qh [B,H,S,64], Kh [B,H,S,64], Vt [B,H,64,Spad]) (+ kmax2 fp32 [B*H, Spad/64] = max ||k||^2 per 64-key tile)."""
     _need_cuda(qkv)
     assert qkv.dtype == torch.bfloat16 and qkv.is_contiguous()
     B, S, _ = qkv.shape
@@ -104,7 +104,7 @@ def qk_norm_rope(qkv, H, n_text, qn_w, qn_b, kn_w, kn_b, eps, cos, sin, q_scale,
     Qh = torch.empty(B, H, S, 64, dtype=torch.bfloat16, device=qkv.device)
     Kh = torch.empty_like(Qh)
     Vt = torch.empty(B, H, 64, Spad, dtype=torch.bfloat16, device=qkv.device)
-    kmax2 = torch.zeros(B * H, dtype=torch.float32, device=qkv.device) if with_kmax else None
+    kmax2 = torch.empty(B * H, Spad // 64, dtype=torch.float32, device=qkv.device) if with_kmax else None
     rc = _lib.load().aether_qk_norm_rope(_lib.ptr(qkv), B, S, H, n_text, _lib.ptr(qn_w), _lib.ptr(qn_b), _lib.ptr(kn_w),
                                          _lib.ptr(kn_b), float(eps), _lib.ptr(cos), _lib.ptr(sin), float(q_scale),
                                          _lib.ptr(Qh), _lib.ptr(Kh), _lib.ptr(Vt), Spad, _lib.ptr(kmax2),
@@ -115,7 +115,7 @@ def qk_norm_rope(qkv, H, n_text, qn_w, qn_b, kn_w, kn_b, eps, cos, sin, q_scale,
 
 def flash_attn_fwd(Qh, Kh, Vt, flags=0, kmax2=None):
     """Qh,Kh [B,H,S,64] (softmax scale x log2(e) folded into Qh: _lib.ATTN_Q_SCALE), Vt [B,H,64,Spad] -> O [B,S,H*64].
-    kmax2 fp32 [B*H]: upper bound of ||k||^2 per (batch, head) enabling the bounded-score soft-max path."""
+    kmax2 fp32 [B*H, Spad/64]: upper bound of ||k||^2 per (batch, head, 64-key tile) enabling the bounded-score soft-max path."""
     _need_cuda(Qh, Kh, Vt)
     B, H, S, d = Qh.shape
     assert d == 64 and Qh.is_contiguous() and Kh.is_contiguous() and Vt.is_contiguous()

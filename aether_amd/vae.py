@@ -131,6 +131,8 @@ class AetherVAE:
         self.tile_overlap_factor_width = 1 / 5
         self._pool: Dict[tuple, torch.Tensor] = {}
         self._taps: Dict[tuple, torch.Tensor] = {}
+        self._splitk_ws: Optional[torch.Tensor] = None       # fp32 scratch for split-K partial tiles (allocated on first use)
+        self.splitk_ws_bytes = 96 << 20
         self._loaded = False
 
     # ------------------------------------------------------------------------------------------------
@@ -303,9 +305,13 @@ class AetherVAE:
         kt, kh, kw = conv.ksize if len(conv.ksize) == 3 else (1,) + conv.ksize
         taps = self._tap_table(kt, kh, kw, iH, iW, iC)
         out = torch.empty(NB, oT, oH, oW, conv.cout_pad, dtype=torch.bfloat16, device=self.device)
+        if self._splitk_ws is None and self.splitk_ws_bytes:
+            self._splitk_ws = torch.empty(self.splitk_ws_bytes // 4, dtype=torch.float32, device=self.device)
         rc = self._lib.aether_conv_gemm_bf16(vol.data_ptr(), NB, iT, iH, iW, iC, oT, oH, oW, stride, taps.data_ptr(), taps.numel(),
                                              conv.w.data_ptr(), conv.cout_pad, out.data_ptr(), conv.cout_pad, conv.b.data_ptr(),
-                                             _lib.ptr(residual), conv.cout_pad if residual is not None else 0, self._flags, self._stream())
+                                             _lib.ptr(residual), conv.cout_pad if residual is not None else 0,
+                                             _lib.ptr(self._splitk_ws), self.splitk_ws_bytes if self._splitk_ws is not None else 0,
+                                             self._flags, self._stream())
         _lib.check(rc, "aether_conv_gemm_bf16")
         return out
 

@@ -97,23 +97,21 @@ int aether_unpatchify(const void* Y, int ldy, void* out, int B, int F, int Cout,
  * (V transposed, Spad = roundup(S,64), pad columns zeroed).  Rows [0,n_text) of each batch are text rows
  * (no RoPE); cos,sin fp32 [S-n_text, 64].  Q is additionally multiplied by q_scale in fp32 before its single rounding
  * to bf16; the attention kernel expects q_scale = log2(e)/sqrt(64) (scores in the log2 domain).
- * kmax2 (fp32 [B*H], may be NULL): atomically max-accumulates ||k||^2 of every (batch, head) — the caller zeroes it
- * beforehand; it feeds the bounded-score path of aether_flash_attn_fwd. */
+ * kmax2 (fp32 [B*H, Spad/64], may be NULL): receives max ||k||^2 over every 64-key tile of every (batch, head), taken on the
+ * rounded bf16 keys; it feeds the bounded-score path of aether_flash_attn_fwd. */
 int aether_qk_norm_rope(const void* qkv, int B, int S, int H, int n_text, const float* qn_w, const float* qn_b,
                         const float* kn_w, const float* kn_b, float eps, const float* cos_t, const float* sin_t,
                         float q_scale, void* Qh, void* Kh, void* Vt, int Spad, float* kmax2, void* stream);
 
-#define AETHER_ATTN_PINGPONG 16   /* flags bit 4: ping-pong kernel (one workgroup per CU, the two waves of a SIMD alternate
-                                     an MFMA stage and a soft-max stage)                                                  */
+#define AETHER_ATTN_PIPELINED 16  /* flags bit 4: software-pipelined kernel (one workgroup per CU; inside each wave the soft-max
+                                     of tile j is interleaved with the MFMAs of P·V(j-1) and K(j+1)·Qᵀ)                    */
 #define AETHER_ATTN_EXACT_MAX 32  /* flags bit 5: ignore kmax2, always run the exact online soft-max                      */
-#define AETHER_ATTN_PRIO_MFMA 64  /* flags bits 6-7 (ping-pong only): 1 = s_setprio 1 in the MFMA stage, 2 = in the      */
-#define AETHER_ATTN_PRIO_VALU 128 /*                                   soft-max stage, 0 = no priority                    */
 
 /* Non-causal flash attention, head_dim 64: O[b,s,h*64+d] = softmax_2(Qh·Khᵀ)·V where softmax_2 uses base 2, i.e.
  * Qh must carry softmax_scale·log2(e) (see aether_qk_norm_rope).  Replaces F.scaled_dot_product_attention in
  * CogVideoXAttnProcessor2_0.  Qh,Kh [B,H,S,64], Vt [B,H,64,Spad], O bf16 [B,S,H*64].
- * kmax2 (fp32 [B*H] or NULL): upper bound of ||k||^2 per (batch, head).  A wave whose rows all satisfy
- * ||q||·sqrt(kmax2) <= 64 runs soft-max without the running maximum (scores are bounded, exp2 cannot overflow or
+ * kmax2 (fp32 [B*H, Spad/64] or NULL): upper bound of ||k||^2 per (batch, head, 64-key tile).  A wave whose rows all satisfy
+ * ||q||·sqrt(max over tiles of kmax2) <= 64 runs soft-max without the running maximum (scores are bounded, exp2 cannot overflow or
  * underflow, soft-max is shift invariant); every other wave, and every wave when kmax2 is NULL, runs the exact online
  * soft-max.  flags: AETHER_GEMM_WIDE_STORE (16-byte epilogue stores), AETHER_ATTN_*. */
 int aether_flash_attn_fwd(const void* Qh, const void* Kh, const void* Vt, void* O, int B, int H, int S, int Spad,
@@ -130,10 +128,13 @@ int aether_flash_attn_fwd(const void* Qh, const void* Kh, const void* Vt, void* 
  * (3x3 stride 1 on [NB, oT, oH+2, oW+2, iC]; 3x3 stride 2 on [NB, oT, 2*oH+1, 2*oW+1, iC]) and conv_shortcut (1x1x1).
  * tap_off: device int32 [n_taps], element offset of K step k inside the padded volume (tap base + 64*channel block);
  * W bf16 [Cout, n_taps*64] with the matching K order (tap-major, then channel); iC % 64 == 0; Cout % 32 == 0.
- * R (bf16 [M, Cout], ldr) is added when non-NULL (ResNet skip). */
+ * R (bf16 [M, Cout], ldr) is added when non-NULL (ResNet skip).
+ * splitk_ws (fp32 scratch of splitk_ws_bytes, may be NULL): launches with <= 128 output tiles (the deep low-resolution
+ * layers, K = 27*512) split their K loop over up to 256/tiles workgroups per tile; the fp32 partial tiles are summed in
+ * slice order (deterministic) by a finalize kernel that also applies bias / R and rounds to bf16. */
 int aether_conv_gemm_bf16(const void* X, int NB, int iT, int iH, int iW, int iC, int oT, int oH, int oW, int stride_hw,
                           const int* tap_off, int n_taps, const void* W, int Cout, void* C, int ldc, const float* bias,
-                          const void* R, int ldr, int flags, void* stream);
+                          const void* R, int ldr, float* splitk_ws, size_t splitk_ws_bytes, int flags, void* stream);
 
 /* Explicit im2col for the thin first convolutions (encoder conv_in 3->128, decoder conv_in 16->512):
  * x is a strided [Cin, T_all, H_all, W_all] tensor (element strides sC,sT,sH,sW); the crop starts at frame t0,

@@ -197,20 +197,20 @@ def test_qk_norm_rope(cuda, hip_lib, B, H, S, n_text):
     _bf16_close(Kh, k, "Kh")
     assert torch.equal(Vt.cpu()[..., :S].float(), v.transpose(2, 3))      # transpose only: bit exact
     assert (Vt.cpu()[..., S:] == 0).all()
-    # max ||k||^2 per (batch, head): an fp32 reduction of the pre-rounding values (1e-4 covers the summation order)
-    ref_kmax2 = (k * k).sum(-1).amax(-1).reshape(-1)
-    assert torch.allclose(kmax2.cpu(), ref_kmax2, rtol=1e-4), (kmax2.cpu(), ref_kmax2)
-    # and it bounds the rounded keys the attention kernel will see, with the kernel's 2 % slack
-    assert ((Kh.float().cpu() ** 2).sum(-1).amax(-1).reshape(-1) <= kmax2.cpu() * 1.02).all()
+    # max ||k||^2 per (batch, head, 64-key tile), reduced from the bf16 Kh the attention kernel reads (1e-5: fp32 summation order)
+    Spad = Vt.shape[-1]
+    n2 = torch.zeros(B * H, Spad)
+    n2[:, :S] = (Kh.float().cpu() ** 2).sum(-1).reshape(B * H, S)
+    ref_kmax2 = n2.reshape(B * H, Spad // 64, 64).amax(-1)
+    assert torch.allclose(kmax2.cpu(), ref_kmax2, rtol=1e-5), (kmax2.cpu(), ref_kmax2)
     # without the optional output the signature is unchanged
     Qh2, Kh2, Vt2 = ops.qk_norm_rope(c(qkv), H, n_text, c(qn_w), c(qn_b), c(kn_w), c(kn_b), 1e-6, c(cos), c(sin), ATTN_Q_SCALE)
     torch.cuda.synchronize()
     assert torch.equal(Qh2, Qh) and torch.equal(Kh2, Kh) and torch.equal(Vt2, Vt)
 
 
-# attention kernel variants: lock-step (narrow / wide store), ping-pong without priority / MFMA-stage priority /
-# soft-max-stage priority
-ATTN_FLAGS = [0, 1, 16 | 1, 16 | 1 | 64, 16 | 128]
+# attention kernel variants: lock-step (narrow / wide store), software-pipelined (narrow / wide store)
+ATTN_FLAGS = [0, 1, 16, 16 | 1]
 
 
 def _attn_case(B, H, S, seed, q_gain=1.0):
@@ -227,7 +227,8 @@ def _attn_case(B, H, S, seed, q_gain=1.0):
     # fp32 reference on the SAME rounded operands: softmax over base 2 of qb.kb
     ref = torch.nn.functional.scaled_dot_product_attention(qb.float(), kb.float(), vb.float(), scale=math.log(2.0))
     ref = ref.transpose(1, 2).reshape(B, S, H * 64)
-    kmax2 = (kb.float() ** 2).sum(-1).amax(-1).reshape(-1).contiguous()
+    # per-(batch, head, 64-key tile) bound, as aether_qk_norm_rope emits it (here simply the head maximum everywhere)
+    kmax2 = (kb.float() ** 2).sum(-1).amax(-1).reshape(-1, 1).repeat(1, Spad // 64).contiguous()
     return qb, kb, vt, ref, kmax2
 
 

@@ -39,6 +39,32 @@ def test_conv_gemm_vs_conv3d(cuda, hip_lib, cin, cout, kt):
     assert _rel(out[..., :cout].cpu(), ref) < 6e-3
 
 
+@pytest.mark.parametrize("cin,cout,NB,T,H,W", [(512, 512, 1, 2, 10, 18), (512, 512, 2, 3, 30, 45), (256, 128, 1, 2, 20, 36)])
+def test_conv_gemm_split_k(cuda, hip_lib, cin, cout, NB, T, H, W):
+    """Deep low-resolution layers (K = 27*512 = 216 K tiles, a handful of output tiles): the split-K path (fp32 partial
+    tiles summed in slice order + finalize) against conv3d, against the single-pass kernel, and run-to-run bit-identical."""
+    from aether_amd.vae import _Conv
+    g = torch.Generator().manual_seed(cin + H)
+    x = torch.randn(NB, cin, T + 2, H, W, generator=g).to(torch.bfloat16)
+    w = (torch.randn(cout, cin, 3, 3, 3, generator=g) / (cin * 27) ** 0.5).to(torch.bfloat16)
+    b = torch.randn(cout, generator=g)
+    res = torch.randn(NB, T, H, W, cout, generator=g).to(torch.bfloat16)
+    ref = F.conv3d(x.float(), w.float(), b, padding=(0, 1, 1)).permute(0, 2, 3, 4, 1) + res.float()
+    conv = _Conv(w, b, cuda)
+    vol = torch.zeros(NB, T + 2, H + 2, W + 2, cin, dtype=torch.bfloat16, device=cuda)
+    vol[:, :, 1:-1, 1:-1] = x.permute(0, 2, 3, 4, 1).to(cuda)
+    vae = _vae(cuda)
+    out_split = vae._conv(vol, conv, (T, H, W), 1, res.to(cuda))
+    out_split2 = vae._conv(vol, conv, (T, H, W), 1, res.to(cuda))
+    vae_single = _vae(cuda)
+    vae_single.splitk_ws_bytes = 0                      # no workspace -> single-pass kernel
+    out_single = vae_single._conv(vol, conv, (T, H, W), 1, res.to(cuda))
+    torch.cuda.synchronize()
+    assert _rel(out_split.cpu(), ref) < 6e-3 and _rel(out_single.cpu(), ref) < 6e-3
+    assert torch.equal(out_split, out_split2)           # deterministic reduction order
+    assert _rel(out_split.cpu(), out_single.cpu()) < 4e-3   # same math, different fp32 summation order + one rounding
+
+
 def test_conv_stride2_vs_conv2d(cuda, hip_lib):
     from aether_amd.vae import _Conv
     g = torch.Generator().manual_seed(9)

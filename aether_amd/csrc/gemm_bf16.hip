@@ -36,7 +36,8 @@ extern "C" int aether_gemm_bf16(const void* A, int lda, const void* W, int ldw, 
                                 void* stream) {
     int rc = gemm_check_common(A, W, C, R, bias, gate_vid, gate_txt, M, N, K, lda, ldw, ldc, ldr, epilogue);
     if (rc) return rc;
-    if ((size_t)M * (size_t)lda >= (1ull << 32)) return aether_set_error(AETHER_ERR_SHAPE, "gemm: operand exceeds 32-bit element offsets");
+    if ((size_t)M * (size_t)lda * 2 >= (1ull << 32) || (size_t)N * (size_t)ldw * 2 >= (1ull << 32))
+        return aether_set_error(AETHER_ERR_SHAPE, "gemm: operand exceeds the 4 GiB a buffer descriptor can address");
     GemmArgs p = {};
     p.A = (const bf16_t*)A; p.lda = lda;
     p.W = (const bf16_t*)W; p.ldw = ldw;
@@ -50,6 +51,8 @@ extern "C" int aether_gemm_bf16(const void* A, int lda, const void* W, int ldw, 
     p.tiles_m = (M + 255) / 256;
     p.tiles_n = (N + 255) / 256;
     p.stagger = (flags >> 2) & 3;
+    p.a_bytes = (unsigned)(((size_t)(M - 1) * lda + K) * 2);
+    p.w_bytes = (unsigned)(((size_t)(N - 1) * ldw + K) * 2);
     dim3 grid(p.tiles_m * p.tiles_n), block(512);
     hipStream_t s = (hipStream_t)stream;
     const bool wide = (flags & AETHER_GEMM_WIDE_STORE) != 0;

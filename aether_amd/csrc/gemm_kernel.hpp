@@ -46,6 +46,7 @@ struct GemmArgs {
     int ksplit;                 // 1 = off; otherwise grid = tiles * ksplit and workgroup (tile, slice) accumulates K tiles
                                 // [slice*nk/ksplit, (slice+1)*nk/ksplit) and stores its raw fp32 tile to part[slice][M][N]
     float* part;                // fp32 [ksplit][M][N]; summed in slice order (deterministic) by splitk_finalize_kernel
+    unsigned a_bytes, w_bytes;  // extents of A and W in bytes (< 4 GiB): bounds of the buffer descriptors the LDS-DMA goes through
 };
 
 constexpr int GEMM_BK = 64;
@@ -104,22 +105,29 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
         const int wr = min(n0 + r * 64 + srow, p.N - 1);
         w_off[r] = (unsigned)wr * (unsigned)p.ldw + schunk * 8;
     }
-    char* const lds_stage = smem + wave * 1024;
+    // LDS-DMA through buffer descriptors: per-lane byte offsets are loop invariant, the K advance is a scalar offset (a
+    // table load for the gathered convolution taps) — no VALU, no v_readfirstlane in the main loop.
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    char* const lds_stage = smem + wave_s * 1024;
     const bool w_active = (BN >= 64) || (srow < BN);   // BN = 32: only half of the threads carry weight rows
+    const buf_rsrc_t a_rsrc = make_buf_rsrc(p.A, p.a_bytes), w_rsrc = make_buf_rsrc(p.W, p.w_bytes);
+#pragma unroll
+    for (int r = 0; r < A_ROUNDS; ++r) a_off[r] *= 2;
+#pragma unroll
+    for (int r = 0; r < W_ROUNDS; ++r) w_off[r] *= 2;
 
     const int nk_all = p.K / GEMM_BK;
     const int k_first = (p.ksplit > 1) ? (int)((long)kslice * nk_all / p.ksplit) : 0;     // this workgroup's K tiles:
     const int nk = ((p.ksplit > 1) ? (int)((long)(kslice + 1) * nk_all / p.ksplit) : nk_all) - k_first;   // [k_first, k_first + nk)
     auto stage = [&](int kt, int buf) {
         kt += k_first;
-        const bf16_t* Ak = p.A + (GATHER ? p.tap_off[kt] : kt * GEMM_BK);
-        const bf16_t* Wk = p.W + kt * GEMM_BK;
+        const unsigned a_soff = 2u * (unsigned)(GATHER ? p.tap_off[kt] : kt * GEMM_BK), w_soff = 2u * (unsigned)(kt * GEMM_BK);
         char* dst = lds_stage + buf * BUF_BYTES;
 #pragma unroll
-        for (int r = 0; r < A_ROUNDS; ++r) glds16(Ak + a_off[r], dst + r * 8192);
+        for (int r = 0; r < A_ROUNDS; ++r) bglds16(a_rsrc, a_off[r], a_soff, dst + r * 8192);
         if (w_active) {
 #pragma unroll
-            for (int r = 0; r < W_ROUNDS; ++r) glds16(Wk + w_off[r], dst + A_TILE + r * 8192);
+            for (int r = 0; r < W_ROUNDS; ++r) bglds16(w_rsrc, w_off[r], w_soff, dst + A_TILE + r * 8192);
         }
     };
     const int late_wave = __builtin_amdgcn_readfirstlane(wave >> 2);   // waves 4-7 share SIMDs with waves 0-3
@@ -147,10 +155,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
         // ---- "ping-pong" main loop -------------------------------------------------------------------------------
         // The two waves that share a SIMD (w and w+4) alternate roles every slot, phase-locked by s_barrier: while one
         // issues its MFMAs for KSPS k-steps (fragments already in registers) the other reads its next fragments from
-        // LDS; the LDS-DMA pieces of the next K tile are issued in the shadow of the MFMAs.  With KSPS = 1 (8 slots / tile):
+        // LDS and issues the LDS-DMA pieces of the next K tile.  With KSPS = 1 (8 slots / tile):
         //   group 0 (waves 0-3):  L0 C0 L1 C1 L2 C2 L3 C3        group 1 (waves 4-7):  C3' L0 C0 L1 C1 L2 C2 L3
         // (C3' = last compute slot of the previous tile); KSPS = 2 halves the number of slots (16 MFMAs per slot).
-        // The matrix pipe of every SIMD always has exactly one wave feeding it.
+        // The matrix pipe of every SIMD always has exactly one wave feeding it; the loading wave also issues the LDS-DMA.
         auto pingpong = [&](auto ksps_tag) {
             constexpr int KSPS = decltype(ksps_tag)::value;
             constexpr int NSLOT = 4 / KSPS;            // compute slots per K tile
@@ -166,32 +174,35 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
             };
             // DMA pieces of tile kt split in NPART parts, one per early compute slot
             constexpr int NPART = (KSPS == 1) ? 3 : 1;
+            // past the last K tile the staging re-fetches that tile into the buffer nobody reads any more: no branch around
+            // the DMA pieces, uniform vmcnt accounting
             auto stage_part = [&](int kt, int buf, int part) {
-                kt += k_first;
-                const bf16_t* Ak = p.A + (GATHER ? p.tap_off[kt] : kt * GEMM_BK);
-                const bf16_t* Wk = p.W + kt * GEMM_BK;
+                kt = min(kt, nk - 1) + k_first;
+                const unsigned a_soff = 2u * (unsigned)(GATHER ? p.tap_off[kt] : kt * GEMM_BK), w_soff = 2u * (unsigned)(kt * GEMM_BK);
                 char* dst = lds_stage + buf * BUF_BYTES;
                 constexpr int NP = A_ROUNDS + W_ROUNDS;
 #pragma unroll
                 for (int r = 0; r < A_ROUNDS; ++r)
-                    if (r * NPART / NP == part) glds16(Ak + a_off[r], dst + r * 8192);
+                    if (r * NPART / NP == part) bglds16(a_rsrc, a_off[r], a_soff, dst + r * 8192);
                 if (w_active) {
 #pragma unroll
                     for (int r = 0; r < W_ROUNDS; ++r)
-                        if ((A_ROUNDS + r) * NPART / NP == part) glds16(Wk + w_off[r], dst + A_TILE + r * 8192);
+                        if ((A_ROUNDS + r) * NPART / NP == part) bglds16(w_rsrc, w_off[r], w_soff, dst + A_TILE + r * 8192);
                 }
             };
-            auto mma_with_stage = [&](bool do_stage, int kt, int part) {
+            // The DMA pieces are issued by the wave in its LOAD slot, after its fragment reads: issuing one costs the issuing
+            // wave 60-185 cycles (profiles/r01_gemm_ablation.json: the loop runs 20-35 % faster with the DMA removed), which
+            // in the MFMA slot came straight out of the matrix pipe's time; VMEM issue of the loading wave overlaps the
+            // partner's MFMAs.
+            auto mma = [&]() {
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int k = 0; k < KSPS; ++k)
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        if (k == 0 && mt == MT / 2 && do_stage) stage_part(kt, kt & 1, part);
+                    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[k][nt], xf[k][mt], acc[mt][nt], 0, 0, 0);
-                    }
                 __builtin_amdgcn_s_setprio(0);
             };
             auto slot_end = [&]() {
@@ -199,16 +210,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
             };
+            // Slot k of tile kt is global slot 8kt+2k (+1 for the compute half) for group 0 and one later for group 1, so the
+            // buffer of tile kt+1 (last read in the load slots of tile kt-1, which end at global slot 8kt-1 for group 1) is
+            // free for the whole of tile kt; its DMA is waited for (vmcnt(0)) before the barrier that ends global slot 8kt+7.
             if (late_wave == 0) {
                 for (int kt = 0; kt < nk; ++kt) {
                     const char* base = smem + (kt & 1) * BUF_BYTES;
-                    const bool has_next = kt + 1 < nk;
 #pragma unroll
                     for (int sl = 0; sl < NSLOT; ++sl) {
                         load_frags(base, sl);
+                        if (sl < NPART) stage_part(kt + 1, (kt + 1) & 1, sl);
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         slot_end();
-                        mma_with_stage(has_next && sl < NPART, kt + 1, sl);
+                        mma();
                         if (sl == NSLOT - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         slot_end();
                     }
@@ -216,23 +230,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
             } else {
                 for (int kt = 0; kt < nk; ++kt) {
                     const char* base = smem + (kt & 1) * BUF_BYTES;
-                    const bool has_next = kt + 1 < nk;
-                    if (kt > 0) mma_with_stage(has_next, kt + 1, 0);   // last compute slot of the previous tile
-                    else if (has_next) stage_part(kt + 1, (kt + 1) & 1, 0);
+                    if (kt > 0) mma();                             // last compute slot of the previous tile
                     slot_end();
 #pragma unroll
                     for (int sl = 0; sl < NSLOT; ++sl) {
                         load_frags(base, sl);
+                        if (sl < NPART) stage_part(kt + 1, (kt + 1) & 1, sl);
                         if (sl == NSLOT - 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         slot_end();
                         if (sl < NSLOT - 1) {
-                            mma_with_stage(has_next && sl + 1 < NPART, kt + 1, sl + 1);
+                            mma();
                             slot_end();
                         }
                     }
                 }
-                mma_with_stage(false, 0, 0);                                   // last compute slot of the last tile
+                mma();                                             // last compute slot of the last tile
             }
         };
         if (p.stagger == 1) pingpong(std::integral_constant<int, 1>{});

@@ -171,7 +171,8 @@ extern "C" int aether_conv_gemm_bf16(const void* X, int NB, int iT, int iH, int 
     if (!tap_off || n_taps <= 0) return aether_set_error(AETHER_ERR_ARG, "conv_gemm: tap table required");
     if (iC % 64 != 0) return aether_set_error(AETHER_ERR_SHAPE, "conv_gemm: input channels must be a multiple of 64");
     if (stride_hw != 1 && stride_hw != 2) return aether_set_error(AETHER_ERR_SHAPE, "conv_gemm: stride must be 1 or 2");
-    if ((size_t)NB * iT * iH * iW * iC >= (1ull << 32)) return aether_set_error(AETHER_ERR_SHAPE, "conv_gemm: input volume exceeds 32-bit element offsets");
+    if ((size_t)NB * iT * iH * iW * iC * 2 >= (1ull << 32) || (size_t)Cout * K * 2 >= (1ull << 32))
+        return aether_set_error(AETHER_ERR_SHAPE, "conv_gemm: input volume exceeds the 4 GiB a buffer descriptor can address");
     if (splitk_ws != nullptr && (((uintptr_t)splitk_ws) & 15)) return aether_set_error(AETHER_ERR_ALIGN, "conv_gemm: split-K workspace must be 16-byte aligned");
     GemmArgs p = {};
     p.A = (const bf16_t*)X; p.lda = 0;
@@ -185,6 +186,8 @@ extern "C" int aether_conv_gemm_bf16(const void* X, int NB, int iT, int iH, int 
     p.oT = oT; p.oH = oH; p.oW = oW; p.iT = iT; p.iH = iH; p.iW = iW; p.iC = iC; p.stride_hw = stride_hw;
     const bool wide = (flags & AETHER_GEMM_WIDE_STORE) != 0;
     p.stagger = (flags >> 2) & 3;
+    p.a_bytes = (unsigned)((size_t)NB * iT * iH * iW * iC * 2);
+    p.w_bytes = (unsigned)((size_t)Cout * K * 2);
     dim3 block(512);
     // split-K when the output tiles cannot fill the chip (one 128-KiB-LDS workgroup per CU, 256 CUs): the deep layers have
     // K = 27*512 = 216 K tiles walked serially by a handful of workgroups otherwise.  Slices >= 4 K tiles, total <= 256 WGs.

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
     const int nk = ((p.ksplit > 1) ? (int)((long)(kslice + 1) * nk_all / p.ksplit) : nk_all) - k_first;   // [k_first, k_first + nk)
     auto stage = [&](int kt, int buf) {
         kt += k_first;
-        const unsigned a_soff = 2u * (unsigned)(GATHER ? p.tap_off[kt] : kt * GEMM_BK), w_soff = 2u * (unsigned)(kt * GEMM_BK);
+        const unsigned a_soff = 2u * (unsigned)(GATHER ? __builtin_amdgcn_readfirstlane(p.tap_off[kt]) : kt * GEMM_BK), w_soff = 2u * (unsigned)(kt * GEMM_BK);
         char* dst = lds_stage + buf * BUF_BYTES;
 #pragma unroll
         for (int r = 0; r < A_ROUNDS; ++r) bglds16(a_rsrc, a_off[r], a_soff, dst + r * 8192);
@@ -176,9 +176,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
             constexpr int NPART = (KSPS == 1) ? 3 : 1;
             // past the last K tile the staging re-fetches that tile into the buffer nobody reads any more: no branch around
             // the DMA pieces, uniform vmcnt accounting
+            // gathered A: the tap offset of the tile being staged was fetched (scalar load) one tile earlier — a load issued
+            // in the load slot itself would put its latency, and the lgkmcnt wait it shares with the fragment reads, ahead of
+            // every DMA piece
+            // (readfirstlane: hipcc issues the table read as a vector load and would otherwise wrap every DMA piece that uses
+            // it as its scalar offset in a waterfall loop)
+            int tap_stage = GATHER ? __builtin_amdgcn_readfirstlane(p.tap_off[min(1, nk - 1) + k_first]) : 0;   // tile staged during tile 0
+            int tap_ahead = 0;
             auto stage_part = [&](int kt, int buf, int part) {
                 kt = min(kt, nk - 1) + k_first;
-                const unsigned a_soff = 2u * (unsigned)(GATHER ? p.tap_off[kt] : kt * GEMM_BK), w_soff = 2u * (unsigned)(kt * GEMM_BK);
+                const unsigned a_soff = 2u * (unsigned)(GATHER ? tap_stage : kt * GEMM_BK), w_soff = 2u * (unsigned)(kt * GEMM_BK);
                 char* dst = lds_stage + buf * BUF_BYTES;
                 constexpr int NP = A_ROUNDS + W_ROUNDS;
 #pragma unroll
@@ -216,6 +223,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
             if (late_wave == 0) {
                 for (int kt = 0; kt < nk; ++kt) {
                     const char* base = smem + (kt & 1) * BUF_BYTES;
+                    if (GATHER) tap_ahead = p.tap_off[min(kt + 2, nk - 1) + k_first];
 #pragma unroll
                     for (int sl = 0; sl < NSLOT; ++sl) {
                         load_frags(base, sl);
@@ -226,10 +234,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
                         if (sl == NSLOT - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         slot_end();
                     }
+                    if (GATHER) tap_stage = __builtin_amdgcn_readfirstlane(tap_ahead);
                 }
             } else {
                 for (int kt = 0; kt < nk; ++kt) {
                     const char* base = smem + (kt & 1) * BUF_BYTES;
+                    if (GATHER) tap_ahead = p.tap_off[min(kt + 2, nk - 1) + k_first];
                     if (kt > 0) mma();                             // last compute slot of the previous tile
                     slot_end();
 #pragma unroll
@@ -244,6 +254,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
                             slot_end();
                         }
                     }
+                    if (GATHER) tap_stage = __builtin_amdgcn_readfirstlane(tap_ahead);
                 }
                 mma();                                             // last compute slot of the last tile
             }

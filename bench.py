@@ -42,6 +42,26 @@ def flops_per_launch(cls: str, B: int, S: int, D: int, FF: int) -> float:
     }.get(cls, 0.0)
 
 
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_dit_step_v2.json")   # tools/profile_dit.sh + tools/summarize_rocprof.py
+
+
+def pmc_traffic(kernel_class: str):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (FETCH_SIZE and WRITE_SIZE in separate passes; read side doubled per the gfx950 correction of
+    /opt/skills/guides/MI355X_MICROARCH.md §HBM; the write side is the raw counter).  None if no summary is committed."""
+    needle = {"attention": "flash_attn", "gemm_qkv": "gemm_bf16_kernel<2, 4, 4, 2, 0", "gemm_ff1": "gemm_bf16_kernel<2, 4, 4, 2, 1",
+              "gemm_ff2": "gemm_bf16_kernel<2, 4, 4, 2, 2", "gemm_out": "gemm_bf16_kernel<2, 4, 4, 2, 2"}.get(kernel_class)
+    try:
+        with open(PMC_SUMMARY) as f:
+            pmc = json.load(f)["pmc"]
+    except (OSError, KeyError, ValueError):
+        return None, None
+    for name, e in pmc.items():
+        if needle and needle in name and "hbm_read_bytes_per_launch_corrected" in e:
+            return e["hbm_read_bytes_per_launch_corrected"] + e.get("hbm_write_bytes_per_launch_raw", 0.0), os.path.relpath(PMC_SUMMARY, ROOT)
+    return None, None
+
+
 def cpu_baseline(cfg_overrides, S_video_shape, seconds_budget=30.0):
     """fp32 oracle (oracle/dit.py) on the host cores: ONE transformer block at the full token count, extrapolated to
     the 42-block forward (blocks are identical; embeddings/final layers are <0.1 % of the flops)."""
@@ -200,6 +220,7 @@ def main():
         dom_ms, dom_n = prof[dom]
         fl = flops_per_launch(dom, B, S, D, FF)
         ach = fl / (dom_ms / dom_n * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic(dom)
         line = {
             "metric": "denoise-steps/s (41f 480x720 clip, 11x60x90 latent, B=%d through the DiT)" % B,
             "value": steps_per_s, "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -210,7 +231,8 @@ def main():
                        "scheduler": "CogVideoXDPMScheduler(50 steps)", "valid": args.layers == 42},
             "mfma_frac_whole_step": steps_per_s / world * B * 260.8e12 / (MFMA_PEAK_TFLOPS * 1e12),
             "roofline": {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": dom_ms / dom_n, "launches": dom_n,
+                         "frac": ach / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC)",
+                         "traffic_source": traffic_src, "avg_launch_ms": dom_ms / dom_n, "launches": dom_n,
                          "algorithmic_flops_per_launch": fl},
             "kernel_ms_per_step": {k: round(ms / args.steps, 3) for k, (ms, _) in prof.items()},
             "kernel_tflops": {k: round(flops_per_launch(k, B, S, D, FF) * n / (ms * 1e-3) / 1e12, 1) for k, (ms, n) in prof.items()

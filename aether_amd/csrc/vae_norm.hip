@@ -104,26 +104,38 @@ __global__ __launch_bounds__(256) void groupnorm_finalize_kernel(const float* __
 }
 
 // cond[nb, zv, 0, c] = by[c] + sum_j wy[c,j] zq[nb,zv,j];   cond[nb, zv, 1, c] = bb[c] + sum_j wb[c,j] zq[nb,zv,j]
-__global__ __launch_bounds__(256) void spatial_cond_kernel(const unsigned short* __restrict__ zq, int zV, int zC, int C,
+// A thread keeps the 2 x zC weights of its channel in registers and walks the block's voxels; the zC latent values of a voxel
+// are wave-uniform (staged through LDS once per block), the two outputs of consecutive threads are consecutive floats.
+constexpr int SC_ZC = 16;       // latent channels (CogVideoX: 16)
+constexpr int SC_VOX = 64;      // voxels per block
+__global__ __launch_bounds__(256) void spatial_cond_kernel(const unsigned short* __restrict__ zq, int zC, int C,
                                                            const float* __restrict__ wy, const float* __restrict__ by,
                                                            const float* __restrict__ wb, const float* __restrict__ bb,
                                                            float* __restrict__ cond, int total_vox) {
-    const int per_vox = C;
-    const long total = (long)total_vox * per_vox;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % per_vox);
-        const long v = idx / per_vox;
-        const unsigned short* z = zq + v * zC;
-        float y = by[c], b = bb[c];
-        for (int j = 0; j < zC; ++j) {
-            const float zj = bf16_bits_to_f32(z[j]);
-            y += wy[(size_t)c * zC + j] * zj;
-            b += wb[(size_t)c * zC + j] * zj;
-        }
-        cond[(v * 2 + 0) * C + c] = y;
-        cond[(v * 2 + 1) * C + c] = b;
+    __shared__ float zs[SC_VOX][SC_ZC];
+    const int v0 = blockIdx.x * SC_VOX;
+    const int nv = min(SC_VOX, total_vox - v0);
+    for (int i = threadIdx.x; i < nv * SC_ZC; i += 256) {
+        const int v = i / SC_ZC, j = i - v * SC_ZC;
+        zs[v][j] = (j < zC) ? bf16_bits_to_f32(zq[(size_t)(v0 + v) * zC + j]) : 0.f;
     }
-    (void)zV;
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float wyr[SC_ZC], wbr[SC_ZC];
+#pragma unroll
+        for (int j = 0; j < SC_ZC; ++j) {
+            wyr[j] = (j < zC) ? wy[(size_t)c * zC + j] : 0.f;
+            wbr[j] = (j < zC) ? wb[(size_t)c * zC + j] : 0.f;
+        }
+        const float y0 = by[c], b0 = bb[c];
+        for (int v = 0; v < nv; ++v) {
+            float y = y0, b = b0;
+#pragma unroll
+            for (int j = 0; j < SC_ZC; ++j) { y += wyr[j] * zs[v][j]; b += wbr[j] * zs[v][j]; }   // same order as the plain loop
+            cond[((size_t)(v0 + v) * 2 + 0) * C + c] = y;
+            cond[((size_t)(v0 + v) * 2 + 1) * C + c] = b;
+        }
+    }
 }
 
 struct GnApplyArgs {
@@ -204,12 +216,10 @@ extern "C" int aether_groupnorm_stats(const void* x, int NB, int V, int C, int G
 extern "C" int aether_spatial_cond(const void* zq, int NB, int zV, int zC, int C, const float* wy, const float* by, const float* wb,
                                    const float* bb, float* cond, void* stream) {
     if (!zq || !wy || !by || !wb || !bb || !cond) return aether_set_error(AETHER_ERR_ARG, "spatial_cond: null pointer");
-    if (NB <= 0 || zV <= 0 || zC <= 0 || C <= 0) return aether_set_error(AETHER_ERR_SHAPE, "spatial_cond: bad sizes");
-    const long total = (long)NB * zV * C;
-    long blocks = (total + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(spatial_cond_kernel, dim3((int)blocks), dim3(256), 0, AE_STREAM, (const unsigned short*)zq, zV, zC, C, wy, by, wb, bb,
-                       cond, NB * zV);
+    if (NB <= 0 || zV <= 0 || zC <= 0 || zC > SC_ZC || C <= 0) return aether_set_error(AETHER_ERR_SHAPE, "spatial_cond: bad sizes (latent channels <= 16)");
+    const int total_vox = NB * zV;
+    hipLaunchKernelGGL(spatial_cond_kernel, dim3((total_vox + SC_VOX - 1) / SC_VOX), dim3(256), 0, AE_STREAM, (const unsigned short*)zq, zC, C, wy, by,
+                       wb, bb, cond, total_vox);
     return aether_check_launch("spatial_cond");
 }
 

@@ -39,7 +39,7 @@ SIGNATURES = {
     "aether_last_error": (C.c_char_p, []),
     "aether_version": (_i, []),
     "aether_check_device": (_i, []),
-    "aether_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _fp, _i, _vp, _i, _fp, _fp, _i, _i, _i, _i, _vp]),
+    "aether_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _fp, _i, _vp, _i, _fp, _fp, _i, _i, _i, _fp, _sz, _i, _vp]),
     "aether_layernorm_modulate": (_i, [_vp, _i, _vp, _i, _i, _i, _f, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _vp]),
     "aether_gemv_rows": (_i, [_fp, _i, _i, _vp, _fp, _fp, _i, _i, _i, _vp]),
     "aether_timestep_sinusoid": (_i, [_fp, _i, _i, _fp, _vp]),

@@ -29,11 +29,12 @@ const char* const kRequired[] = {
     "ff1_w", "ff1_b", "ff2_w", "ff2_b", "normf_w", "normf_b", "normo_w", "normo_b", "proj_w", "proj_b"};
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+constexpr size_t kSplitKBytes = (size_t)256 * 256 * 256 * sizeof(float);   // fp32 partial tiles of a GEMM tail launch (<= 256 workgroups)
 
 struct Plan {
     int D, FF, Nt, Nv, S, M, Spad, Kp, Np, Nmod, PH, PW;
     size_t off_x, off_xn, off_qkv, off_qh, off_kh, off_vt, off_attn, off_ff, off_patch, off_tsin, off_t1, off_temb,
-        off_mod, off_proj, off_kmax, total;
+        off_mod, off_proj, off_kmax, off_splitk, total;
 };
 
 Plan make_plan(const AetherDitConfig& c, int B, int F, int H, int W) {
@@ -67,6 +68,7 @@ Plan make_plan(const AetherDitConfig& c, int B, int F, int H, int W) {
     p.off_mod = take((size_t)B * p.Nmod * 4);
     p.off_proj = take((size_t)B * p.Nv * p.Np * 2);
     p.off_kmax = take((size_t)B * c.num_heads * (p.Spad / 64) * 4);
+    p.off_splitk = take(kSplitKBytes);
     p.total = o;
     return p;
 }
@@ -180,7 +182,7 @@ extern "C" int aether_dit_forward(AetherDit* h, const void* hidden, const void* 
     char* qh = ws + p.off_qh; char* kh = ws + p.off_kh; char* vt = ws + p.off_vt;
     char* attn = ws + p.off_attn; char* ff = ws + p.off_ff; char* patch = ws + p.off_patch;
     float* tsin = (float*)(ws + p.off_tsin); float* t1 = (float*)(ws + p.off_t1); float* temb = (float*)(ws + p.off_temb);
-    float* mod = (float*)(ws + p.off_mod); char* proj = ws + p.off_proj; float* kmax = (float*)(ws + p.off_kmax);
+    float* mod = (float*)(ws + p.off_mod); char* proj = ws + p.off_proj; float* kmax = (float*)(ws + p.off_kmax); float* skws = (float*)(ws + p.off_splitk);
     const int D = p.D, FF = p.FF, S = p.S, M = p.M, Nt = p.Nt, Nv = p.Nv, L = c.num_layers, fl = c.flags;
     auto W_ = [&](const char* n) { return (const char*)h->w[n]; };
     auto Wf = [&](const char* n) { return (const float*)h->w[n]; };
@@ -192,10 +194,10 @@ extern "C" int aether_dit_forward(AetherDit* h, const void* hidden, const void* 
         char* xb = x + (size_t)b * S * D * 2;
         AE_TRY(aether_gemm_bf16((const char*)text + (size_t)b * Nt * c.text_dim * 2, c.text_dim, W_("text_w"), c.text_dim, xb, D,
                                 Nt, D, c.text_dim, Wf("text_b"), pos ? AETHER_EPI_BIAS_GATE_RES : AETHER_EPI_BIAS, pos, D,
-                                nullptr, nullptr, 0, 0, 0, fl, stream));
+                                nullptr, nullptr, 0, 0, 0, skws, kSplitKBytes, fl, stream));
         AE_TRY(aether_gemm_bf16(patch + (size_t)b * Nv * p.Kp * 2, p.Kp, W_("patch_w"), p.Kp, xb + (size_t)Nt * D * 2, D, Nv, D,
                                 p.Kp, Wf("patch_b"), pos ? AETHER_EPI_BIAS_GATE_RES : AETHER_EPI_BIAS,
-                                pos ? pos + (size_t)Nt * D * 2 : nullptr, D, nullptr, nullptr, 0, 0, 0, fl, stream));
+                                pos ? pos + (size_t)Nt * D * 2 : nullptr, D, nullptr, nullptr, 0, 0, 0, skws, kSplitKBytes, fl, stream));
     }
     // ---- timestep embedding and every AdaLN modulation vector of the forward in one GEMV ---------
     AE_TRY(aether_timestep_sinusoid(timesteps, B, D, tsin, stream));
@@ -213,18 +215,18 @@ extern "C" int aether_dit_forward(AetherDit* h, const void* hidden, const void* 
         AE_RUN(AETHER_PROF_LN, aether_layernorm_modulate(x, D, xn, D, M, D, c.norm_eps, Wf("ln1_w") + (size_t)i * D, Wf("ln1_b") + (size_t)i * D,
                                          m1, m1 + D, m1 + 3 * D, m1 + 4 * D, p.Nmod, S, Nt, stream));
         AE_RUN(AETHER_PROF_GEMM_QKV, aether_gemm_bf16(xn, D, W_("qkv_w") + (size_t)i * 3 * D * D * 2, D, qkv, 3 * D, M, 3 * D, D,
-                                Wf("qkv_b") + (size_t)i * 3 * D, AETHER_EPI_BIAS, nullptr, 0, nullptr, nullptr, 0, 0, 0, fl, stream));
+                                Wf("qkv_b") + (size_t)i * 3 * D, AETHER_EPI_BIAS, nullptr, 0, nullptr, nullptr, 0, 0, 0, skws, kSplitKBytes, fl, stream));
         AE_RUN(AETHER_PROF_QKROPE, aether_qk_norm_rope(qkv, B, S, c.num_heads, Nt, Wf("qn_w") + i * 64, Wf("qn_b") + i * 64, Wf("kn_w") + i * 64,
                                    Wf("kn_b") + i * 64, c.qk_norm_eps, rope_cos, rope_sin, q_scale, qh, kh, vt, p.Spad, kmax, stream));
         AE_RUN(AETHER_PROF_ATTN, aether_flash_attn_fwd(qh, kh, vt, attn, B, c.num_heads, S, p.Spad, kmax, fl, stream));
         AE_RUN(AETHER_PROF_GEMM_O, aether_gemm_bf16(attn, D, W_("o_w") + (size_t)i * D * D * 2, D, x, D, M, D, D, Wf("o_b") + (size_t)i * D,
-                                AETHER_EPI_BIAS_GATE_RES, x, D, m1 + 2 * D, m1 + 5 * D, p.Nmod, S, Nt, fl, stream));
+                                AETHER_EPI_BIAS_GATE_RES, x, D, m1 + 2 * D, m1 + 5 * D, p.Nmod, S, Nt, skws, kSplitKBytes, fl, stream));
         AE_RUN(AETHER_PROF_LN, aether_layernorm_modulate(x, D, xn, D, M, D, c.norm_eps, Wf("ln2_w") + (size_t)i * D, Wf("ln2_b") + (size_t)i * D,
                                          m2, m2 + D, m2 + 3 * D, m2 + 4 * D, p.Nmod, S, Nt, stream));
         AE_RUN(AETHER_PROF_GEMM_FF1, aether_gemm_bf16(xn, D, W_("ff1_w") + (size_t)i * FF * D * 2, D, ff, FF, M, FF, D, Wf("ff1_b") + (size_t)i * FF,
-                                AETHER_EPI_BIAS_GELU, nullptr, 0, nullptr, nullptr, 0, 0, 0, fl, stream));
+                                AETHER_EPI_BIAS_GELU, nullptr, 0, nullptr, nullptr, 0, 0, 0, skws, kSplitKBytes, fl, stream));
         AE_RUN(AETHER_PROF_GEMM_FF2, aether_gemm_bf16(ff, FF, W_("ff2_w") + (size_t)i * D * FF * 2, FF, x, D, M, D, FF, Wf("ff2_b") + (size_t)i * D,
-                                AETHER_EPI_BIAS_GATE_RES, x, D, m2 + 2 * D, m2 + 5 * D, p.Nmod, S, Nt, fl, stream));
+                                AETHER_EPI_BIAS_GATE_RES, x, D, m2 + 2 * D, m2 + 5 * D, p.Nmod, S, Nt, skws, kSplitKBytes, fl, stream));
     }
 
     // ---- norm_final -> norm_out (AdaLayerNorm, shift first) -> proj_out -> un-patchify -----------
@@ -235,7 +237,7 @@ extern "C" int aether_dit_forward(AetherDit* h, const void* hidden, const void* 
                                      S, Nt, stream));
     for (int b = 0; b < B; ++b)
         AE_TRY(aether_gemm_bf16(x + ((size_t)b * S + Nt) * D * 2, D, W_("proj_w"), D, proj + (size_t)b * Nv * p.Np * 2, p.Np, Nv,
-                                p.Np, D, Wf("proj_b"), AETHER_EPI_BIAS, nullptr, 0, nullptr, nullptr, 0, 0, 0, fl, stream));
+                                p.Np, D, Wf("proj_b"), AETHER_EPI_BIAS, nullptr, 0, nullptr, nullptr, 0, 0, 0, skws, kSplitKBytes, fl, stream));
     AE_TRY(aether_unpatchify(proj, p.Np, out, B, F, c.out_channels, H, W, c.patch_size, stream));
     return AETHER_OK;
 }

@@ -28,12 +28,57 @@ int gemm_check_common(const void* A, const void* W, const void* C, const void* R
     return AETHER_OK;
 }
 
+// Tail launch finalize: C tile = epi( sum over K slices of the fp32 partial tile ), partials tile-major
+// [slice][tile - tile_base][256][256] (slice order fixed -> deterministic).  One thread = 8 consecutive columns of one row.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_tail_finalize_kernel(GemmArgs p) {
+    constexpr int BM = 256, BN = 256;
+    const int tile = blockIdx.y;                                  // tile - tile_base
+    int tile_m, tile_n;
+    gemm_tile_coords(p.tile_base + tile, p.tiles_m, p.tiles_n, tile_m, tile_n);
+    const int item = blockIdx.x * 256 + threadIdx.x;              // BM * BN / 8 items per tile
+    const int row = item / (BN / 8), oct = item - row * (BN / 8);
+    const int m = tile_m * BM + row, n = tile_n * BN + oct * 8;
+    if (m >= p.M || n >= p.N) return;
+    const size_t slice = (size_t)p.ntile_launch * BM * BN;
+    const float* src = p.part + (size_t)tile * BM * BN + (size_t)row * BN + oct * 8;
+    f32x4 a0 = *(const f32x4*)src, a1 = *(const f32x4*)(src + 4);
+    for (int s = 1; s < p.ksplit; ++s) {
+        a0 += *(const f32x4*)(src + s * slice);
+        a1 += *(const f32x4*)(src + s * slice + 4);
+    }
+    float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    if (p.bias != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += p.bias[n + e];
+    }
+    if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
+    }
+    if (EPI == EPI_BIAS_GATE_RES) {
+        if (p.gate_vid != nullptr) {
+            const int b = m / p.rows_per_batch, t = m - b * p.rows_per_batch;
+            const float* gate = (t < p.n_text ? p.gate_txt : p.gate_vid) + (size_t)b * p.gate_bstride;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= gate[n + e];
+        }
+        if (p.R != nullptr) {
+            const u16x8 r = *(const u16x8*)(p.R + (size_t)m * p.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bf16_bits_to_f32(r[e]);
+        }
+    }
+    *(uint4*)(p.C + (size_t)m * p.ldc + n) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                                       pack_bf16x2(v[6], v[7]));
+}
+
 }  // namespace aether
 
 extern "C" int aether_gemm_bf16(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
                                 const float* bias, int epilogue, const void* R, int ldr, const float* gate_vid,
-                                const float* gate_txt, int gate_bstride, int rows_per_batch, int n_text, int flags,
-                                void* stream) {
+                                const float* gate_txt, int gate_bstride, int rows_per_batch, int n_text, float* splitk_ws,
+                                size_t splitk_ws_bytes, int flags, void* stream) {
     int rc = gemm_check_common(A, W, C, R, bias, gate_vid, gate_txt, M, N, K, lda, ldw, ldc, ldr, epilogue);
     if (rc) return rc;
     if ((size_t)M * (size_t)lda * 2 >= (1ull << 32) || (size_t)N * (size_t)ldw * 2 >= (1ull << 32))
@@ -53,19 +98,48 @@ extern "C" int aether_gemm_bf16(const void* A, int lda, const void* W, int ldw, 
     p.stagger = (flags >> 2) & 3;
     p.a_bytes = (unsigned)(((size_t)(M - 1) * lda + K) * 2);
     p.w_bytes = (unsigned)(((size_t)(N - 1) * ldw + K) * 2);
-    dim3 grid(p.tiles_m * p.tiles_n), block(512);
+    dim3 block(512);
     hipStream_t s = (hipStream_t)stream;
     const bool wide = (flags & AETHER_GEMM_WIDE_STORE) != 0;
-#define LAUNCH(E)                                                                                          \
-    do {                                                                                                   \
-        if (wide) hipLaunchKernelGGL((gemm_bf16_kernel<2, 4, 4, 2, E, true, false>), grid, block, 0, s, p); \
-        else hipLaunchKernelGGL((gemm_bf16_kernel<2, 4, 4, 2, E, false, false>), grid, block, 0, s, p);     \
+    // Tail balancing: one 128-KiB-LDS workgroup per CU means ceil(tiles/256) rounds; when the last round would hold only a few
+    // tiles (qkv: 2124 = 8*256 + 76, ff-up: 2832 = 11*256 + 16) those tiles go to a second launch that splits their K loop over
+    // floor(256/rest) workgroups each (fp32 partial tiles, summed in slice order by gemm_tail_finalize_kernel with the epilogue).
+    const int NCU = 256, tiles = p.tiles_m * p.tiles_n, nk = K / GEMM_BK;
+    const int full = tiles / NCU * NCU, rest = tiles - full;
+    int ks = (rest > 0 && rest <= NCU / 2) ? NCU / rest : 1;
+    if (ks > nk / 4) ks = nk / 4;
+    if (splitk_ws == nullptr || full == 0 || (size_t)ks * rest * 256 * 256 * sizeof(float) > splitk_ws_bytes || (((uintptr_t)splitk_ws) & 15) ||
+        false)
+        ks = 1;
+    if (ks < 2) ks = 1;
+    p.ntile_launch = (ks > 1) ? full : tiles;
+#define LAUNCH(E)                                                                                                        \
+    do {                                                                                                                 \
+        dim3 grid(p.ntile_launch * p.ksplit);                                                                            \
+        if (wide) hipLaunchKernelGGL((gemm_bf16_kernel<2, 4, 4, 2, E, true, false>), grid, block, 0, s, p);               \
+        else hipLaunchKernelGGL((gemm_bf16_kernel<2, 4, 4, 2, E, false, false>), grid, block, 0, s, p);                   \
     } while (0)
-    switch (epilogue) {
-        case EPI_BIAS: LAUNCH(EPI_BIAS); break;
-        case EPI_BIAS_GELU: LAUNCH(EPI_BIAS_GELU); break;
-        default: LAUNCH(EPI_BIAS_GATE_RES); break;
+#define LAUNCH_EPI()                                        \
+    switch (epilogue) {                                     \
+        case EPI_BIAS: LAUNCH(EPI_BIAS); break;             \
+        case EPI_BIAS_GELU: LAUNCH(EPI_BIAS_GELU); break;   \
+        default: LAUNCH(EPI_BIAS_GATE_RES); break;          \
     }
+    p.ksplit = 1;
+    LAUNCH_EPI();
+    rc = aether_check_launch("gemm_bf16");
+    if (rc || ks == 1) return rc;
+    p.tile_base = full; p.ntile_launch = rest; p.ksplit = ks; p.part = splitk_ws; p.part_tiled = 1;
+    LAUNCH_EPI();
+    rc = aether_check_launch("gemm_bf16 (tail)");
+    if (rc) return rc;
+    dim3 fgrid(256 * 256 / 8 / 256, rest);
+    switch (epilogue) {
+        case EPI_BIAS: hipLaunchKernelGGL((gemm_tail_finalize_kernel<EPI_BIAS>), fgrid, dim3(256), 0, s, p); break;
+        case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_tail_finalize_kernel<EPI_BIAS_GELU>), fgrid, dim3(256), 0, s, p); break;
+        default: hipLaunchKernelGGL((gemm_tail_finalize_kernel<EPI_BIAS_GATE_RES>), fgrid, dim3(256), 0, s, p); break;
+    }
+#undef LAUNCH_EPI
 #undef LAUNCH
-    return aether_check_launch("gemm_bf16");
+    return aether_check_launch("gemm_tail_finalize");
 }

@@ -46,11 +46,25 @@ struct GemmArgs {
     int ksplit;                 // 1 = off; otherwise grid = tiles * ksplit and workgroup (tile, slice) accumulates K tiles
                                 // [slice*nk/ksplit, (slice+1)*nk/ksplit) and stores its raw fp32 tile to part[slice][M][N]
     float* part;                // fp32 [ksplit][M][N]; summed in slice order (deterministic) by splitk_finalize_kernel
+    // a launch may cover only the tiles [tile_base, tile_base + ntile_launch) of the tiles_m x tiles_n grid (DiT tail launch):
+    int tile_base, ntile_launch;
+    int part_tiled;             // split-K partials stored tile-major [slice][tile - tile_base][BM][BN] instead of [slice][M][N]
     unsigned a_bytes, w_bytes;  // extents of A and W in bytes (< 4 GiB): bounds of the buffer descriptors the LDS-DMA goes through
 };
 
 constexpr int GEMM_BK = 64;
 constexpr int GEMM_GROUP_M = 4;
+
+// tile id -> (tile_m, tile_n): groups of GEMM_GROUP_M row tiles x all column tiles, row tile fastest inside a group
+AE_DEV void gemm_tile_coords(int wgid, int tiles_m, int tiles_n, int& tile_m, int& tile_n) {
+    const int per_group = GEMM_GROUP_M * tiles_n;
+    const int group = wgid / per_group;
+    const int first_m = group * GEMM_GROUP_M;
+    const int gsz = min(GEMM_GROUP_M, tiles_m - first_m);
+    const int in_group = wgid - group * per_group;
+    tile_m = first_m + in_group % gsz;
+    tile_n = in_group / gsz;
+}
 
 template <int WM, int WN, int MT, int NT, int EPI, bool WIDE_STORE, bool GATHER>
 __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
@@ -71,16 +85,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
     const int l32 = lane & 31;
 
     // ---- tile assignment: XCD-aware remap, then groups of GEMM_GROUP_M row tiles x all column tiles ------------
-    const int nwg = p.tiles_m * p.tiles_n;
+    const int nwg = p.ntile_launch;
     const int kslice = (p.ksplit > 1) ? (int)blockIdx.x / nwg : 0;
-    const int wgid = xcd_remap((int)blockIdx.x - kslice * nwg, nwg);
-    const int per_group = GEMM_GROUP_M * p.tiles_n;
-    const int group = wgid / per_group;
-    const int first_m = group * GEMM_GROUP_M;
-    const int gsz = min(GEMM_GROUP_M, p.tiles_m - first_m);
-    const int in_group = wgid - group * per_group;
-    const int tile_m = first_m + in_group % gsz;
-    const int tile_n = in_group / gsz;
+    const int wgid = xcd_remap((int)blockIdx.x - kslice * nwg, nwg) + p.tile_base;
+    int tile_m, tile_n;
+    gemm_tile_coords(wgid, p.tiles_m, p.tiles_n, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---- staging addresses ---------------------------------------------------------------------------------------
@@ -285,19 +294,21 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
     // ---- epilogue ------------------------------------------------------------------------------------------------
     // acc[mt][nt][r] = C[m][n], m = m0 + (wm*MT + mt)*32 + l32,  n = n0 + (wn*NT + nt)*32 + 8*(r>>2) + 4*hi + (r&3)
     if (p.ksplit > 1) {   // split-K: raw fp32 partial tile; bias / residual / rounding happen in splitk_finalize_kernel
-        float* part = p.part + (size_t)kslice * p.M * p.N;
+        float* part = p.part_tiled ? p.part + ((size_t)kslice * nwg + (wgid - p.tile_base)) * (BM * BN) : p.part + (size_t)kslice * p.M * p.N;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int m = m0 + (wm * MT + mt) * 32 + l32;
+            const int mrow = (wm * MT + mt) * 32 + l32;          // row inside the tile
+            const int m = m0 + mrow;
             if (m >= p.M) continue;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const int nbase = n0 + (wn * NT + nt) * 32;
-                if (nbase >= p.N) continue;
+                const int ncol = (wn * NT + nt) * 32;              // column group inside the tile
+                if (n0 + ncol >= p.N) continue;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 v = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
-                    *(f32x4*)(part + (size_t)m * p.N + nbase + 8 * g + 4 * hi) = v;
+                    if (p.part_tiled) *(f32x4*)(part + (size_t)mrow * BN + ncol + 8 * g + 4 * hi) = v;
+                    else *(f32x4*)(part + (size_t)m * p.N + n0 + ncol + 8 * g + 4 * hi) = v;
                 }
             }
         }

@@ -204,7 +204,7 @@ extern "C" int aether_conv_gemm_bf16(const void* X, int NB, int iT, int iH, int 
 #define LAUNCH_CFG(WM_, WN_, MT_, NT_, BM_, BN_)                                                                                   \
     do {                                                                                                                            \
         p.tiles_m = (M + BM_ - 1) / BM_; p.tiles_n = (Cout + BN_ - 1) / BN_;                                                         \
-        p.ksplit = pick_ksplit(p.tiles_m * p.tiles_n); p.part = splitk_ws;                                                           \
+        p.ksplit = pick_ksplit(p.tiles_m * p.tiles_n); p.part = splitk_ws; p.ntile_launch = p.tiles_m * p.tiles_n;                  \
         dim3 grid(p.tiles_m * p.tiles_n * p.ksplit);                                                                               \
         if (R) { if (wide) hipLaunchKernelGGL((gemm_bf16_kernel<WM_, WN_, MT_, NT_, EPI_BIAS_GATE_RES, true, true>), grid, block, 0, AE_STREAM, p); \
                  else hipLaunchKernelGGL((gemm_bf16_kernel<WM_, WN_, MT_, NT_, EPI_BIAS_GATE_RES, false, true>), grid, block, 0, AE_STREAM, p); }    \

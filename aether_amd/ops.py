@@ -18,8 +18,9 @@ def _need_cuda(*ts):
 
 
 def gemm_bf16(A, W, bias=None, epilogue=AETHER_EPI_BIAS, R=None, gate_vid=None, gate_txt=None, rows_per_batch=0, n_text=0,
-              out=None, flags=0):
-    """out[M,N] = epi(A[M,K] @ W[N,K]^T); A,W,R bf16; bias/gates fp32. gate_*: [B, N] (row stride = stride(0))."""
+              out=None, flags=0, splitk_ws=None):
+    """out[M,N] = epi(A[M,K] @ W[N,K]^T); A,W,R bf16; bias/gates fp32. gate_*: [B, N] (row stride = stride(0)).
+    splitk_ws: optional fp32 scratch (>= 64 MiB) enabling the split-K tail launch."""
     _need_cuda(A, W, bias, R, gate_vid, gate_txt)
     assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and A.dim() == 2 and W.dim() == 2
     assert A.stride(1) == 1 and W.stride(1) == 1
@@ -31,8 +32,8 @@ def gemm_bf16(A, W, bias=None, epilogue=AETHER_EPI_BIAS, R=None, gate_vid=None, 
     lib = _lib.load()
     rc = lib.aether_gemm_bf16(_lib.ptr(A), A.stride(0), _lib.ptr(W), W.stride(0), _lib.ptr(out), out.stride(0), M, N, K,
                               _lib.ptr(bias), epilogue, _lib.ptr(R), R.stride(0) if R is not None else 0,
-                              _lib.ptr(gate_vid), _lib.ptr(gate_txt), gstride, rows_per_batch, n_text, flags,
-                              _lib.current_stream())
+                              _lib.ptr(gate_vid), _lib.ptr(gate_txt), gstride, rows_per_batch, n_text, _lib.ptr(splitk_ws),
+                              splitk_ws.numel() * 4 if splitk_ws is not None else 0, flags, _lib.current_stream())
     _lib.check(rc, "aether_gemm_bf16")
     return out
 

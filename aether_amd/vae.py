@@ -321,7 +321,7 @@ class AetherVAE:
         out = torch.empty(*x.shape[:-1], conv.cout_pad, dtype=torch.bfloat16, device=self.device)
         rc = self._lib.aether_gemm_bf16(x.data_ptr(), x.shape[-1], conv.w.data_ptr(), conv.w.shape[1], out.data_ptr(), conv.cout_pad,
                                         rows, conv.cout_pad, conv.w.shape[1], conv.b.data_ptr(), _lib.AETHER_EPI_BIAS, None, 0, None, None,
-                                        0, 0, 0, self._flags, self._stream())
+                                        0, 0, 0, None, 0, self._flags, self._stream())
         _lib.check(rc, "aether_gemm_bf16")
         return out
 

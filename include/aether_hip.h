@@ -57,11 +57,14 @@ int aether_check_device(void);
  * GEMM over 2x2 patches; text_proj; proj_out).  K % 64 == 0, N % 32 == 0, ld* % 8 == 0.
  * bias fp32 [N] or NULL.  R (bf16 [M,N], ldr) and the gates apply to AETHER_EPI_BIAS_GATE_RES only:
  * row m belongs to batch b = m / rows_per_batch and is a text row iff (m % rows_per_batch) < n_text;
- * gate = (text ? gate_txt : gate_vid)[b*gate_bstride + n]; NULL gates mean 1.  R may alias C. */
+ * gate = (text ? gate_txt : gate_vid)[b*gate_bstride + n]; NULL gates mean 1.  R may alias C.
+ * splitk_ws (fp32 scratch of splitk_ws_bytes >= 64 MiB, may be NULL): tail balancing — when the last round of 256 tiles would
+ * hold <= 128 tiles, those tiles run as a second launch with their K loop split over floor(256/rest) workgroups each and a
+ * finalize kernel (fixed summation order) applies the epilogue.  Without scratch the GEMM is a single launch. */
 int aether_gemm_bf16(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
                      const float* bias, int epilogue, const void* R, int ldr, const float* gate_vid,
-                     const float* gate_txt, int gate_bstride, int rows_per_batch, int n_text, int flags,
-                     void* stream);
+                     const float* gate_txt, int gate_bstride, int rows_per_batch, int n_text, float* splitk_ws,
+                     size_t splitk_ws_bytes, int flags, void* stream);
 
 /* y = LayerNorm(x; eps)·w + b, then optionally y·(1+scale)+shift with per-batch, per-row-type
  * modulation vectors (fp32).  Replaces CogVideoXLayerNormZero.norm + modulation, norm_final, and

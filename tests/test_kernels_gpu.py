@@ -91,6 +91,48 @@ def test_gemm_gate_residual_inplace(cuda, hip_lib, flags):
     _bf16_close(x, ref, "gemm+gate+res")
 
 
+@pytest.mark.parametrize("epi", ["bias", "gelu", "gate_res"])
+def test_gemm_tail_split_k(cuda, hip_lib, epi):
+    """17 x 16 = 272 tiles = one full round of 256 + 16: with scratch the 16 tail tiles run as a second launch whose K loop
+    is split over 4 workgroups each (fp32 partial tiles + finalize with the epilogue).  Same result as the single launch
+    up to the fp32 summation order, identical run to run, and rows of the ragged last row tile are handled."""
+    from aether_amd import ops
+    g = torch.Generator().manual_seed(17)
+    M, N, K = 17 * 256 - 40, 4096, 1024
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g)
+    y = A.float() @ W.float().t() + bias
+    kw = {}
+    if epi == "bias":
+        ref, code = y, ops.AETHER_EPI_BIAS
+    elif epi == "gelu":
+        ref, code = torch.nn.functional.gelu(y, approximate="tanh"), ops.AETHER_EPI_BIAS_GELU
+    else:
+        R = torch.randn(M, N, generator=g).to(torch.bfloat16)
+        gate = torch.randn(1, 2 * N, generator=g)
+        n_text = 100
+        gsel = torch.where((torch.arange(M) < n_text)[:, None], gate[0, N:], gate[0, :N])
+        ref, code = R.float() + gsel * y, ops.AETHER_EPI_BIAS_GATE_RES
+        gc = gate.to(cuda)
+        kw = dict(gate_vid=gc[:, :N], gate_txt=gc[:, N:], rows_per_batch=M, n_text=n_text)
+    ws = torch.empty(16 << 20, dtype=torch.float32, device=cuda)      # 64 MiB
+    outs = []
+    for use_ws in (None, ws, ws):
+        if epi == "gate_res":
+            x = R.to(cuda).clone()
+            ops.gemm_bf16(A.to(cuda), W.to(cuda), bias.to(cuda), code, R=x, out=x, flags=5, splitk_ws=use_ws, **kw)
+            outs.append(x)
+        else:
+            outs.append(ops.gemm_bf16(A.to(cuda), W.to(cuda), bias.to(cuda), code, flags=5, splitk_ws=use_ws))
+    torch.cuda.synchronize()
+    for o in outs:
+        _bf16_close(o, ref, f"gemm tail split-K {epi}")
+    assert torch.equal(outs[1], outs[2])                               # deterministic
+    diff_rows = (outs[0] != outs[1]).any(dim=1).nonzero().flatten()
+    assert diff_rows.numel() == 0 or diff_rows.min() >= 16 * 256 - 1024   # only tiles of the last row-tile group can differ
+
+
 def test_gemm_rejects_bad_shapes(cuda, hip_lib):
     from aether_amd import ops
     A = torch.zeros(64, 100, dtype=torch.bfloat16, device=cuda)

@@ -50,6 +50,7 @@ def main():
         return (torch.randn(*shape, generator=g, device=dev, dtype=torch.float32) * scale).to(dtype)
 
     only = set(x for x in args.only.split(",") if x)
+    splitk_ws = torch.empty(16 << 20, dtype=torch.float32, device=dev)   # 64 MiB scratch for the split-K tail launch
     # ---- GEMMs -------------------------------------------------------------------------------
     for name, (M, N, K, epi) in ({} if (only and "gemm" not in only) else {
         "gemm_qkv": (S, 3 * D, D, ops.AETHER_EPI_BIAS),
@@ -63,11 +64,11 @@ def main():
         out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
         R = rnd(M, N) if epi == ops.AETHER_EPI_BIAS_GATE_RES else None
         gate = rnd(1, 2 * N, dtype=torch.float32) if R is not None else None
-        for flags in (1, 1 | 4, 1 | 8):
+        for flags, use_ws in ((1, False), (1 | 4, False), (1 | 4, True)):
             kw = dict(R=R, gate_vid=gate[:, :N], gate_txt=gate[:, N:], rows_per_batch=M, n_text=226) if R is not None else {}
-            t = timeit(lambda: ops.gemm_bf16(A, W, bias, epi, out=out, flags=flags, **kw))
+            t = timeit(lambda: ops.gemm_bf16(A, W, bias, epi, out=out, flags=flags, splitk_ws=splitk_ws if use_ws else None, **kw))
             tf = 2.0 * M * N * K / t / 1e12
-            res["results"].append({"kernel": name, "flags": flags, "M": M, "N": N, "K": K, "ms": t * 1e3, "TFLOPs": tf,
+            res["results"].append({"kernel": name, "flags": flags, "tail_split_k": use_ws, "M": M, "N": N, "K": K, "ms": t * 1e3, "TFLOPs": tf,
                                    "frac_mfma_peak": tf / 2500.0})
             print(res["results"][-1], flush=True)
         del A, W, out, R

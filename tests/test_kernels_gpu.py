@@ -91,8 +91,9 @@ def test_gemm_gate_residual_inplace(cuda, hip_lib, flags):
     _bf16_close(x, ref, "gemm+gate+res")
 
 
+@pytest.mark.parametrize("gflags", [5, 9])
 @pytest.mark.parametrize("epi", ["bias", "gelu", "gate_res"])
-def test_gemm_tail_split_k(cuda, hip_lib, epi):
+def test_gemm_tail_split_k(cuda, hip_lib, epi, gflags):
     """17 x 16 = 272 tiles = one full round of 256 + 16: with scratch the 16 tail tiles run as a second launch whose K loop
     is split over 4 workgroups each (fp32 partial tiles + finalize with the epilogue).  Same result as the single launch
     up to the fp32 summation order, identical run to run, and rows of the ragged last row tile are handled."""
@@ -121,10 +122,10 @@ def test_gemm_tail_split_k(cuda, hip_lib, epi):
     for use_ws in (None, ws, ws):
         if epi == "gate_res":
             x = R.to(cuda).clone()
-            ops.gemm_bf16(A.to(cuda), W.to(cuda), bias.to(cuda), code, R=x, out=x, flags=5, splitk_ws=use_ws, **kw)
+            ops.gemm_bf16(A.to(cuda), W.to(cuda), bias.to(cuda), code, R=x, out=x, flags=gflags, splitk_ws=use_ws, **kw)
             outs.append(x)
         else:
-            outs.append(ops.gemm_bf16(A.to(cuda), W.to(cuda), bias.to(cuda), code, flags=5, splitk_ws=use_ws))
+            outs.append(ops.gemm_bf16(A.to(cuda), W.to(cuda), bias.to(cuda), code, flags=gflags, splitk_ws=use_ws))
     torch.cuda.synchronize()
     for o in outs:
         _bf16_close(o, ref, f"gemm tail split-K {epi}")

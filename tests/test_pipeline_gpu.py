@@ -111,6 +111,25 @@ def test_planning_cfg_end_to_end(world):
     _compare(nat, ref32, ref16, "planning(5 steps, CFG)")
 
 
+def test_prediction_cfg_end_to_end(world):
+    """BASELINE configs[2]: action-conditioned prediction = one observation image + a camera raymap, CFG with the
+    frame-0 condition zeroed in the unconditional branch (P:846-848), dynamic guidance scale (P:880-893)."""
+    video = _video()
+    img = video[0]
+    # a smooth forward-right trajectory raymap (the reference's assets/example_raymaps/*.npy are missing from the mount)
+    tt = np.linspace(0, 1, F, dtype=np.float32)[:, None, None, None]
+    yy, xx = np.mgrid[0:H // 8, 0:W // 8].astype(np.float32)
+    base = np.stack([xx / (W // 8) - 0.5, yy / (H // 8) - 0.5, np.ones_like(xx)], 0)[None]          # ray directions
+    raymap = np.concatenate([base + 0.1 * tt * np.array([1, 0, 0], np.float32)[None, :, None, None],
+                             tt * np.array([0.3, 0.0, 1.0], np.float32)[None, :, None, None] * np.ones_like(base)], 1).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).permute(2, 0, 1)[None] * 2 - 1  # noqa: E731
+    kw = dict(image=t(img), raymap=torch.from_numpy(raymap)[None], num_inference_steps=5)
+    ref32 = _oracle(world, "prediction", torch.float32, generator=torch.Generator().manual_seed(11), **kw)
+    ref16 = _oracle(world, "prediction", torch.bfloat16, generator=torch.Generator().manual_seed(11), **kw)
+    nat = _native(world, "prediction", image=img, raymap=raymap, num_inference_steps=5, generator=torch.Generator().manual_seed(11))
+    _compare(nat, ref32, ref16, "prediction(5 steps, CFG)")
+
+
 def test_device_generator_runs(world):
     """The reference seeds a generator on the compute device (D:578,629): must work and be reproducible."""
     video = _video()

@@ -64,7 +64,7 @@ def main():
         out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
         R = rnd(M, N) if epi == ops.AETHER_EPI_BIAS_GATE_RES else None
         gate = rnd(1, 2 * N, dtype=torch.float32) if R is not None else None
-        for flags, use_ws in ((1, False), (1 | 4, False), (1 | 4, True)):
+        for flags, use_ws in ((1, False), (1 | 4, False), (1 | 4, True), (1 | 8, True)):
             kw = dict(R=R, gate_vid=gate[:, :N], gate_txt=gate[:, N:], rows_per_batch=M, n_text=226) if R is not None else {}
             t = timeit(lambda: ops.gemm_bf16(A, W, bias, epi, out=out, flags=flags, splitk_ws=splitk_ws if use_ws else None, **kw))
             tf = 2.0 * M * N * K / t / 1e12

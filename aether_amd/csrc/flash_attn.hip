@@ -25,12 +25,11 @@
 //   * workgroups are remapped so that one XCD walks the query blocks of one (batch, head) consecutively:
 //     its K/V (3.9 MB at S = 15 076) stays in that XCD's 4 MiB L2.
 //
-// flash_attn_fwd_kernel: one barrier per KV tile, all 8 waves in lock step, 2 workgroups per CU (TLP hides latency).
-// flash_attn_pp_kernel ("ping-pong"): one workgroup per CU; the two waves that share a SIMD (w, w+4) alternate,
-//   phase-locked by s_barrier, between an MFMA stage (P·V of tile j and K·Qᵀ of tile j+1: 16 back-to-back MFMAs fed
-//   purely from registers) and a VALU stage (soft-max of tile j+1, the 16 ds_read_b128 of the next fragments, the
-//   LDS-DMA of tile j+4) — the matrix pipe of every SIMD always has one wave feeding it while its partner does
-//   the soft-max.  4-deep K/V ring in LDS (64 KiB), DMA waits are counted (vmcnt(2)), never drained in the loop.
+// flash_attn_fwd_kernel: one barrier per KV tile, all waves in lock step, 128 VGPRs -> 16 waves per CU (TLP hides latency).
+//   Default.  Launched twice: the first floor(nwg/512)*512 workgroups as 8-wave / 256-row workgroups (two per CU), the
+//   rest — what would be a partly filled last round — as twice as many 4-wave / 128-row workgroups (four per CU), so the
+//   tail costs its share of a round instead of a whole one (2832 workgroups on 512 slots: 5.53 rounds instead of 6).
+// flash_attn_swp_kernel: software-pipelined variant (AETHER_ATTN_PIPELINED), see below.
 #include <type_traits>
 #include <utility>
 #include "common.hpp"
@@ -47,7 +46,8 @@ constexpr float FA_BOUND_SLACK = 1.02f;        // covers the bf16 rounding of k 
 struct FlashArgs {
     const bf16_t* Q; const bf16_t* K; const bf16_t* Vt; bf16_t* O;
     const float* kmax2;   // [B*H][Spad/64] upper bound of ‖k‖² per (batch, head, 64-key tile), or null
-    int H, S, Spad, nqb, nwg;
+    int H, S, Spad, nqb, nwg;   // nqb: query blocks per head at THIS launch's block size; nwg: workgroups of this launch
+    int wg_first;               // index of this launch's first workgroup in (head, query block) order
 };
 
 // ---- pieces shared by the two kernels ---------------------------------------------------------------------------
@@ -174,14 +174,15 @@ AE_DEV void fa_store(const f32x16 (&o)[2], float l_run, const FlashArgs& p, int 
 // =================================================================================================================
 // lock-step kernel: one barrier per KV tile, double-buffered LDS (32 KiB), 2 workgroups per CU
 // =================================================================================================================
-template <bool WIDE_STORE>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))   // <= 128 VGPRs: two workgroups per CU
+// NW waves = NW*32 query rows per workgroup (8 or 4)
+template <bool WIDE_STORE, int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))   // <= 128 VGPRs: 16 waves per CU
 void flash_attn_fwd_kernel(FlashArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * FA_BUF];
     const FaLane L = fa_lane_setup();
     const int tid = threadIdx.x, hi = L.hi;
 
-    const int wgid = xcd_remap(blockIdx.x, p.nwg);
+    const int wgid = xcd_remap(blockIdx.x, p.nwg) + p.wg_first;
     const int bh = wgid / p.nqb;
     const int qb = wgid - bh * p.nqb;
     const int S = p.S;
@@ -191,13 +192,14 @@ void flash_attn_fwd_kernel(FlashArgs p) {
     const bf16_t* Vg = p.Vt + (size_t)bh * FA_D * p.Spad;
 
     // ---- Q fragment (B operand): lane (q = l32, hi) holds Q[q][16ks + 8hi .. +7] -------------------
-    const int qrow = qb * FA_QBLK + L.wave * 32 + L.l32;
+    if (qb * (NW * 32) >= S) return;   // second half of a ragged last 256-row block may be empty (whole workgroup exits)
+    const int qrow = qb * (NW * 32) + L.wave * 32 + L.l32;
     const int qrow_c = min(qrow, S - 1);
     bf16x8 qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(Qg + (size_t)qrow_c * FA_D + 16 * ks + 8 * hi);
 
-    // ---- staging (one 16-byte piece of K and one of Vᵀ per thread per KV tile) ---------------------
+    // ---- staging (512 16-byte pieces of K and of Vᵀ per KV tile: one each per thread at 8 waves, two at 4) ----
     // buffer-descriptor DMA: the per-lane offsets are loop invariant, the tile advance is a scalar offset; K rows >= S
     // of the ragged last tile are out of range of the descriptor (not fetched; their scores are masked below)
     const int srow = tid >> 3;                          // K: key row in tile; Vᵀ: d row
@@ -208,9 +210,13 @@ void flash_attn_fwd_kernel(FlashArgs p) {
     const buf_rsrc_t v_rsrc = make_buf_rsrc(Vg, (unsigned)p.Spad * FA_D * 2);
     const unsigned k_voff = srow * (FA_D * 2) + schunk * 16;
     const unsigned v_voff = (unsigned)srow * p.Spad * 2 + schunk * 16;
+    constexpr int PASSES = 8 / NW;      // row r and r + 32*pass share the swizzle phase ((r >> 1) & 7)
     auto stage = [&](int j, int buf) {
-        bglds16(k_rsrc, k_voff, j * (FA_KVBLK * FA_D * 2), lds_stage + buf * FA_BUF);
-        bglds16(v_rsrc, v_voff, j * (FA_KVBLK * 2), lds_stage + buf * FA_BUF + FA_TILE);
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            bglds16(k_rsrc, k_voff + ps * (NW * 8) * (FA_D * 2), j * (FA_KVBLK * FA_D * 2), lds_stage + buf * FA_BUF + ps * (NW * 1024));
+            bglds16(v_rsrc, v_voff + ps * (NW * 8) * (unsigned)p.Spad * 2, j * (FA_KVBLK * 2), lds_stage + buf * FA_BUF + FA_TILE + ps * (NW * 1024));
+        }
     };
 
     f32x16 o[2];
@@ -495,16 +501,29 @@ extern "C" int aether_flash_attn_fwd(const void* Qh, const void* Kh, const void*
     p.H = H; p.S = S; p.Spad = Spad;
     p.nqb = (S + FA_QBLK - 1) / FA_QBLK;
     p.nwg = p.nqb * B * H;
+    p.wg_first = 0;
     hipStream_t s = (hipStream_t)stream;
     const bool wide = (flags & AETHER_GEMM_WIDE_STORE) != 0;
     dim3 grid(p.nwg), block(512);
     if (flags & AETHER_ATTN_PIPELINED) {
         if (wide) hipLaunchKernelGGL((flash_attn_swp_kernel<true>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((flash_attn_swp_kernel<false>), grid, block, 0, s, p);
-    } else if (wide) {
-        hipLaunchKernelGGL((flash_attn_fwd_kernel<true>), grid, block, 0, s, p);
     } else {
-        hipLaunchKernelGGL((flash_attn_fwd_kernel<false>), grid, block, 0, s, p);
+        // lock-step kernel: 512 resident workgroup slots (2 x 8 waves per CU at 128 VGPRs).  Whole rounds run as 256-row
+        // workgroups; the remainder runs as twice as many 128-row workgroups (4 per CU) so it costs its share of a round.
+        const int slots = 512;
+        const int full = (flags & AETHER_ATTN_NO_TAIL_SPLIT) ? p.nwg : p.nwg / slots * slots;
+        const int rest = p.nwg - full;
+        if (full > 0) {
+            p.nwg = full; p.wg_first = 0;
+            if (wide) hipLaunchKernelGGL((flash_attn_fwd_kernel<true, 8>), dim3(full), dim3(512), 0, s, p);
+            else hipLaunchKernelGGL((flash_attn_fwd_kernel<false, 8>), dim3(full), dim3(512), 0, s, p);
+        }
+        if (rest > 0) {
+            p.nqb *= 2; p.nwg = 2 * rest; p.wg_first = 2 * full;
+            if (wide) hipLaunchKernelGGL((flash_attn_fwd_kernel<true, 4>), dim3(2 * rest), dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((flash_attn_fwd_kernel<false, 4>), dim3(2 * rest), dim3(256), 0, s, p);
+        }
     }
     return aether_check_launch("flash_attn_fwd");
 }

@@ -252,8 +252,9 @@ def test_qk_norm_rope(cuda, hip_lib, B, H, S, n_text):
     assert torch.equal(Qh2, Qh) and torch.equal(Kh2, Kh) and torch.equal(Vt2, Vt)
 
 
-# attention kernel variants: lock-step (narrow / wide store), software-pipelined (narrow / wide store)
-ATTN_FLAGS = [0, 1, 16, 16 | 1]
+# attention kernel variants: lock-step (narrow / wide store; with <= 512 workgroups everything runs as 128-row workgroups),
+# lock-step forced to 256-row workgroups (64), software-pipelined (narrow / wide store)
+ATTN_FLAGS = [0, 1, 64 | 1, 16, 16 | 1]
 
 
 def _attn_case(B, H, S, seed, q_gain=1.0):
@@ -327,6 +328,19 @@ def test_flash_attention_online_max_jump(cuda, hip_lib, flags):
     out = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags)
     torch.cuda.synchronize()
     _bf16_close(out, ref.transpose(1, 2).reshape(B, S, 64), f"flash max-jump flags={flags}", rel=1.5e-2, max_ulp_frac=4.0)
+
+
+def test_flash_attention_two_launches(cuda, hip_lib):
+    """31 heads x 17 query blocks = 527 workgroups: 512 run as 256-row workgroups, the last 15 as 30 128-row workgroups
+    (the second launch) — both halves against the fp32 reference, and bit-identical to the single-launch kernel."""
+    from aether_amd import ops
+    qb, kb, vt, ref, kmax2 = _attn_case(1, 31, 4100, 31)
+    for bound in (None, kmax2.to(cuda)):
+        out = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=1, kmax2=bound)
+        one = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=1 | 64, kmax2=bound)
+        torch.cuda.synchronize()
+        _bf16_close(out, ref, f"flash two launches bounded={bound is not None}", rel=1.5e-2, max_ulp_frac=4.0)
+        assert torch.equal(out, one)        # a row's arithmetic does not depend on the workgroup shape
 
 
 def test_flash_attention_variants_agree_full_size_head(cuda, hip_lib):

@@ -87,7 +87,7 @@ def main():
         vt = rnd(B, H, 64, Spad)
         vt[..., S:] = 0
         kmax2 = (k.float() ** 2).sum(-1).amax(-1).reshape(-1, 1).repeat(1, Spad // 64).contiguous()
-        variants = [(f, bnd) for f in (1, 17) for bnd in (False, True)]
+        variants = [(f, bnd) for f in (1, 1 | 64, 17) for bnd in (False, True)]
         times = {v: [] for v in variants}
         for rnd_i in range(args.attn_rounds):
             for v in variants:

@@ -42,10 +42,10 @@ def flops_per_launch(cls: str, B: int, S: int, D: int, FF: int) -> float:
     }.get(cls, 0.0)
 
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_dit_step_v2.json")   # tools/profile_dit.sh + tools/summarize_rocprof.py
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_dit_step_v3.json")   # tools/profile_dit.sh + tools/summarize_rocprof.py
 
 
-def pmc_traffic(kernel_class: str):
+def pmc_traffic(kernel_class: str, calls_per_forward: int = 42):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
     (FETCH_SIZE and WRITE_SIZE in separate passes; read side doubled per the gfx950 correction of
     /opt/skills/guides/MI355X_MICROARCH.md §HBM; the write side is the raw counter).  None if no summary is committed."""
@@ -56,10 +56,15 @@ def pmc_traffic(kernel_class: str):
             pmc = json.load(f)["pmc"]
     except (OSError, KeyError, ValueError):
         return None, None
+    # one logical launch may be several kernels (attention: 256-row workgroups + the 128-row tail launch): sum them
+    # (the PMC passes profile exactly one forward: `calls_per_forward` logical launches of the class = one per DiT block)
+    tot = 0.0
     for name, e in pmc.items():
         if needle and needle in name and "hbm_read_bytes_per_launch_corrected" in e:
-            return e["hbm_read_bytes_per_launch_corrected"] + e.get("hbm_write_bytes_per_launch_raw", 0.0), os.path.relpath(PMC_SUMMARY, ROOT)
-    return None, None
+            tot += (e["hbm_read_bytes_per_launch_corrected"] + e.get("hbm_write_bytes_per_launch_raw", 0.0)) * e.get("launches", 1)
+    if tot == 0.0:
+        return None, None
+    return tot / calls_per_forward, os.path.relpath(PMC_SUMMARY, ROOT)
 
 
 def cpu_baseline(cfg_overrides, S_video_shape, seconds_budget=30.0):
@@ -220,7 +225,7 @@ def main():
         dom_ms, dom_n = prof[dom]
         fl = flops_per_launch(dom, B, S, D, FF)
         ach = fl / (dom_ms / dom_n * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic(dom)
+        traffic, traffic_src = pmc_traffic(dom, c.num_layers)
         line = {
             "metric": "denoise-steps/s (41f 480x720 clip, 11x60x90 latent, B=%d through the DiT)" % B,
             "value": steps_per_s, "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -18,7 +18,7 @@
 //   * bounded-score fast path: at head_dim 64 the kernel is VALU-issue bound (≈5 VALU slots per score against
 //     16 MFMAs per 2048 scores), so the biggest lever is fewer VALU ops per score.  q and k are LayerNorm outputs,
 //     so |q·k| ≤ ‖q‖·max‖k‖ (Cauchy–Schwarz); aether_qk_norm_rope emits max‖k‖² per (batch, head, 64-key tile).  When that bound
-//     is ≤ 64 for every row of a wave, exp2(s) can neither overflow nor underflow in fp32/bf16 and soft-max is
+//     is ≤ 96 for every row of a wave, exp2(s) can neither overflow nor underflow in fp32/bf16 and soft-max is
 //     shift invariant, so the wave runs p = exp2(s) with NO running maximum, NO subtraction and NO rescale
 //     (1 v_exp + 1 v_add + ½ v_cvt_pk per score).  Otherwise (or when no bound is supplied) it runs the exact
 //     online soft-max with the conditional rescale.  The decision is per wave and wave-uniform.
@@ -40,7 +40,8 @@ namespace aether {
 constexpr int FA_QBLK = 256, FA_KVBLK = 64, FA_D = 64;
 constexpr int FA_TILE = FA_KVBLK * FA_D * 2;  // 8 KiB (K tile) == 8 KiB (Vᵀ tile)
 constexpr int FA_BUF = 2 * FA_TILE;
-constexpr float FA_FAST_BOUND2 = 64.f * 64.f;  // (‖q‖·max‖k‖)² limit of the bounded-score path
+constexpr float FA_FAST_BOUND2 = 96.f * 96.f;  // (‖q‖·max‖k‖)² limit of the bounded-score path: |s| <= 96 keeps every p = exp2(s) a normal
+                                               // fp32 / bf16 number (2^-96 .. 2^96) and every sum below 2^96 · S · max|v| << 2^127
 constexpr float FA_BOUND_SLACK = 1.02f;        // covers the bf16 rounding of k after its norm was taken (2^-8 rel.)
 
 struct FlashArgs {

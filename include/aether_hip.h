@@ -115,7 +115,7 @@ int aether_qk_norm_rope(const void* qkv, int B, int S, int H, int n_text, const 
  * Qh must carry softmax_scale·log2(e) (see aether_qk_norm_rope).  Replaces F.scaled_dot_product_attention in
  * CogVideoXAttnProcessor2_0.  Qh,Kh [B,H,S,64], Vt [B,H,64,Spad], O bf16 [B,S,H*64].
  * kmax2 (fp32 [B*H, Spad/64] or NULL): upper bound of ||k||^2 per (batch, head, 64-key tile).  A wave whose rows all satisfy
- * ||q||·sqrt(max over tiles of kmax2) <= 64 runs soft-max without the running maximum (scores are bounded, exp2 cannot overflow or
+ * ||q||·sqrt(max over tiles of kmax2) <= 96 runs soft-max without the running maximum (scores are bounded, exp2 cannot overflow or
  * underflow, soft-max is shift invariant); every other wave, and every wave when kmax2 is NULL, runs the exact online
  * soft-max.  flags: AETHER_GEMM_WIDE_STORE (16-byte epilogue stores), AETHER_ATTN_*. */
 int aether_flash_attn_fwd(const void* Qh, const void* Kh, const void* Vt, void* O, int B, int H, int S, int Spad,

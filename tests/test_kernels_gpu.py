@@ -290,6 +290,32 @@ def test_flash_attention(cuda, hip_lib, B, H, S, flags, bounded):
     _bf16_close(out, ref, f"flash S={S} flags={flags} bounded={bounded}", rel=1.5e-2, max_ulp_frac=4.0)
 
 
+@pytest.mark.parametrize("flags", [1, 17])
+def test_flash_attention_bounded_near_the_limit(cuda, hip_lib, flags):
+    """Scores spread over almost the whole admitted range (||q||·||k|| = 90 in the log2 domain, so p = exp2(s) spans
+    2^-90 .. 2^90 with no running maximum): still the fp64 soft-max to bf16 accuracy, no overflow / underflow."""
+    from aether_amd import ops
+    g = torch.Generator().manual_seed(90)
+    B, H, S = 1, 2, 1000
+    unit = lambda *sh: torch.nn.functional.normalize(torch.randn(*sh, generator=g), dim=-1)   # noqa: E731
+    q, k = unit(B, H, S, 64) * 9.0, unit(B, H, S, 64) * 10.0
+    k[:, :, 17] = q[:, :, 5] / 9.0 * 10.0            # one score of +90 ...
+    k[:, :, 300] = -q[:, :, 6] / 9.0 * 10.0          # ... and one of -90
+    v = torch.randn(B, H, S, 64, generator=g)
+    qb, kb, vb = q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
+    ref = torch.softmax((qb.double() @ kb.double().transpose(-1, -2)) * math.log(2.0), dim=-1) @ vb.double()
+    vt = torch.zeros(B, H, 64, 1024, dtype=torch.bfloat16)
+    vt[..., :S] = vb.transpose(2, 3)
+    kmax2 = (kb.float() ** 2).sum(-1).amax(-1).reshape(-1, 1).repeat(1, 16).contiguous()
+    assert float((qb.float().norm(dim=-1).max() * kmax2.max().sqrt())) < 96.0 / 1.02 ** 0.5      # inside the bounded path
+    out = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags, kmax2=kmax2.to(cuda))
+    exact = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags | 32, kmax2=kmax2.to(cuda))
+    torch.cuda.synchronize()
+    r = ref.float().transpose(1, 2).reshape(B, S, H * 64)
+    _bf16_close(out, r, "flash bounded near the limit", rel=1.5e-2, max_ulp_frac=4.0)
+    _bf16_close(exact, r, "flash exact near the limit", rel=1.5e-2, max_ulp_frac=4.0)
+
+
 @pytest.mark.parametrize("flags", ATTN_FLAGS)
 def test_flash_attention_bound_gate(cuda, hip_lib, flags):
     """Scores far outside the bounded-score limit (|s| up to ~400 in the log2 domain): exp2(s) without the running

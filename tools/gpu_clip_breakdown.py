@@ -62,6 +62,25 @@ def main():
             d = dict(acc); d["total"] = total; d["other (pre/post-processing, scheduler glue, D2H)"] = total - sum(acc.values())
             res[label] = {k: round(v, 4) for k, v in d.items()}
             print(label, res[label], flush=True)
+    # BASELINE configs[2] / [3]: prediction (image + raymap) and planning (image + goal): 50 steps with CFG (B = 2 through the
+    # DiT) followed, like scripts/demo.py:589-606, by the 4-step post-reconstruction of the predicted clip
+    img = video[0]
+    goal = video[-1]
+    tt = np.linspace(0, 1, 41, dtype=np.float32)[:, None, None, None]
+    yy8, xx8 = np.mgrid[0:60, 0:90].astype(np.float32)
+    rays = np.stack([xx8 / 90 - 0.5, yy8 / 60 - 0.5, np.ones_like(xx8)], 0)[None]
+    raymap = np.concatenate([rays + 0.1 * tt * np.array([1, 0, 0], np.float32)[None, :, None, None],
+                             tt * np.array([0.3, 0.0, 1.0], np.float32)[None, :, None, None] * np.ones_like(rays)], 1).astype(np.float32)
+    for task, kw in (("prediction", dict(image=img, raymap=raymap)), ("planning", dict(image=img, goal=goal))):
+        acc.clear()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out = pipe(task=task, height=480, width=720, num_frames=41, fps=12, generator=torch.Generator(device=dev).manual_seed(42), **kw)
+        pipe(task="reconstruction", video=out.rgb, height=480, width=720, num_frames=41, num_inference_steps=4, guidance_scale=1.0,
+             use_dynamic_cfg=False, fps=12, generator=torch.Generator(device=dev).manual_seed(42))
+        torch.cuda.synchronize(); total = time.perf_counter() - t0
+        d = dict(acc); d["total"] = total; d["other (pre/post-processing, scheduler glue, D2H)"] = total - sum(acc.values())
+        res[f"{task}_50_steps_cfg_plus_post_reconstruction"] = {k: round(v, 4) for k, v in d.items()}
+        print(task, res[f"{task}_50_steps_cfg_plus_post_reconstruction"], flush=True)
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(res, open("gpurun_out/clip_breakdown.json", "w"), indent=1)
 

@@ -175,8 +175,10 @@ AE_DEV void fa_store(const f32x16 (&o)[2], float l_run, const FlashArgs& p, int 
 // =================================================================================================================
 // lock-step kernel: one barrier per KV tile, double-buffered LDS (32 KiB), 2 workgroups per CU
 // =================================================================================================================
-// NW waves = NW*32 query rows per workgroup (8 or 4)
-template <bool WIDE_STORE, int NW>
+// NW waves = NW*32 query rows per workgroup (8 or 4).  PRIO 1 = s_setprio 1 around the two MFMA clusters (a wave finishes its
+// MFMA burst instead of interleaving with the other waves' soft-max VALU, which does not overlap with it anyway): +1.5 %
+// (profiles/r01_attn_variants_v3.json; around the soft-max instead: +0.8 %).
+template <bool WIDE_STORE, int NW, int PRIO = 1>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))   // <= 128 VGPRs: 16 waves per CU
 void flash_attn_fwd_kernel(FlashArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * FA_BUF];
@@ -240,6 +242,7 @@ void flash_attn_fwd_kernel(FlashArgs p) {
             const char* base = smem + cur * FA_BUF;
 
             f32x16 sc[2];
+            if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -250,12 +253,16 @@ void flash_attn_fwd_kernel(FlashArgs p) {
                     sc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[t], 0, 0, 0);
                 }
             }
+            if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
             if (j == nkv - 1 && ragged) fa_mask_tail(sc, j, hi, S);
 
             bf16x8 pf[2][2];
+            if (PRIO == 2) __builtin_amdgcn_s_setprio(1);
             fa_softmax<FAST>(sc, pf, o, m_run, l_run);
+            if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
 
             // ---- O^T += Vᵀ · Pᵀ ----
+            if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -265,6 +272,7 @@ void flash_attn_fwd_kernel(FlashArgs p) {
                         const bf16x8 vf = *(const bf16x8*)(base + dt * 4096 + L.voff[t][s]);
                         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[t][s], o[dt], 0, 0, 0);
                     }
+            if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
             drain_and_barrier();
         }
     };

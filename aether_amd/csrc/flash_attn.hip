@@ -26,9 +26,9 @@
 //     its K/V (3.9 MB at S = 15 076) stays in that XCD's 4 MiB L2.
 //
 // flash_attn_fwd_kernel: one barrier per KV tile, all waves in lock step, 128 VGPRs -> 16 waves per CU (TLP hides latency).
-//   Default.  Launched twice: the first floor(nwg/512)*512 workgroups as 8-wave / 256-row workgroups (two per CU), the
-//   rest — what would be a partly filled last round — as twice as many 4-wave / 128-row workgroups (four per CU), so the
-//   tail costs its share of a round instead of a whole one (2832 workgroups on 512 slots: 5.53 rounds instead of 6).
+//   Default: one launch of 8-wave / 256-row workgroups (two per CU).  AETHER_ATTN_TAIL_SPLIT launches the first
+//   floor(nwg/512)*512 workgroups that way and the rest — a partly filled last round — as twice as many 4-wave / 128-row
+//   workgroups (four per CU); the "rounds" model promises 8 % for 2832 workgroups on 512 slots, the measurement gives < 1 %.
 // flash_attn_swp_kernel: software-pipelined variant (AETHER_ATTN_PIPELINED), see below.
 #include <type_traits>
 #include <utility>
@@ -518,10 +518,11 @@ extern "C" int aether_flash_attn_fwd(const void* Qh, const void* Kh, const void*
         if (wide) hipLaunchKernelGGL((flash_attn_swp_kernel<true>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((flash_attn_swp_kernel<false>), grid, block, 0, s, p);
     } else {
-        // lock-step kernel: 512 resident workgroup slots (2 x 8 waves per CU at 128 VGPRs).  Whole rounds run as 256-row
-        // workgroups; the remainder runs as twice as many 128-row workgroups (4 per CU) so it costs its share of a round.
+        // lock-step kernel: 512 resident workgroup slots (2 x 8 waves per CU at 128 VGPRs).  With AETHER_ATTN_TAIL_SPLIT whole
+        // rounds run as 256-row workgroups and the remainder as twice as many 128-row workgroups (4 per CU); measured gain
+        // <= 1 % (profiles/r01_attn_variants_v2.json), so the default is ONE launch of 256-row workgroups.
         const int slots = 512;
-        const int full = (flags & AETHER_ATTN_NO_TAIL_SPLIT) ? p.nwg : p.nwg / slots * slots;
+        const int full = (flags & AETHER_ATTN_TAIL_SPLIT) ? p.nwg / slots * slots : p.nwg;
         const int rest = p.nwg - full;
         if (full > 0) {
             p.nwg = full; p.wg_first = 0;

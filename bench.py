@@ -42,7 +42,7 @@ def flops_per_launch(cls: str, B: int, S: int, D: int, FF: int) -> float:
     }.get(cls, 0.0)
 
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_dit_step_v3.json")   # tools/profile_dit.sh + tools/summarize_rocprof.py
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_dit_step_v4.json")   # tools/profile_dit.sh + tools/summarize_rocprof.py
 
 
 def pmc_traffic(kernel_class: str, calls_per_forward: int = 42):

@@ -109,7 +109,7 @@ int aether_qk_norm_rope(const void* qkv, int B, int S, int H, int n_text, const 
 #define AETHER_ATTN_PIPELINED 16  /* flags bit 4: software-pipelined kernel (one workgroup per CU; inside each wave the soft-max
                                      of tile j is interleaved with the MFMAs of P·V(j-1) and K(j+1)·Qᵀ)                    */
 #define AETHER_ATTN_EXACT_MAX 32  /* flags bit 5: ignore kmax2, always run the exact online soft-max                      */
-#define AETHER_ATTN_NO_TAIL_SPLIT 64 /* flags bit 6: one launch of 256-row workgroups (no 128-row workgroups for the last round) */
+#define AETHER_ATTN_TAIL_SPLIT 64 /* flags bit 6: workgroups beyond the last full round of 512 run as 128-row workgroups (2nd launch) */
 
 /* Non-causal flash attention, head_dim 64: O[b,s,h*64+d] = softmax_2(Qh·Khᵀ)·V where softmax_2 uses base 2, i.e.
  * Qh must carry softmax_scale·log2(e) (see aether_qk_norm_rope).  Replaces F.scaled_dot_product_attention in

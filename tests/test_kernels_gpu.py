@@ -252,8 +252,8 @@ def test_qk_norm_rope(cuda, hip_lib, B, H, S, n_text):
     assert torch.equal(Qh2, Qh) and torch.equal(Kh2, Kh) and torch.equal(Vt2, Vt)
 
 
-# attention kernel variants: lock-step (narrow / wide store; with <= 512 workgroups everything runs as 128-row workgroups),
-# lock-step forced to 256-row workgroups (64), software-pipelined (narrow / wide store)
+# attention kernel variants: lock-step (narrow / wide store), lock-step with the tail split (64: with <= 512 workgroups
+# everything then runs as 128-row workgroups), software-pipelined (narrow / wide store)
 ATTN_FLAGS = [0, 1, 64 | 1, 16, 16 | 1]
 
 
@@ -362,8 +362,8 @@ def test_flash_attention_two_launches(cuda, hip_lib):
     from aether_amd import ops
     qb, kb, vt, ref, kmax2 = _attn_case(1, 31, 4100, 31)
     for bound in (None, kmax2.to(cuda)):
-        out = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=1, kmax2=bound)
-        one = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=1 | 64, kmax2=bound)
+        out = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=1 | 64, kmax2=bound)
+        one = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=1, kmax2=bound)
         torch.cuda.synchronize()
         _bf16_close(out, ref, f"flash two launches bounded={bound is not None}", rel=1.5e-2, max_ulp_frac=4.0)
         assert torch.equal(out, one)        # a row's arithmetic does not depend on the workgroup shape

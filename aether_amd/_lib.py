@@ -78,6 +78,11 @@ def load():
             f"{_LIB_PATH} is missing: the HIP extension has not been built (run `python -m aether_amd.build`). "
             "aether_amd has no CPU fallback."
         )
+    # PyTorch ships its own libamdhip64 / libhsa-runtime64 (same SONAMEs as /opt/rocm's).  Whichever copy is mapped first serves
+    # the whole process, and the kernels must run in the runtime instance that owns torch's allocations and streams: import
+    # torch BEFORE dlopen-ing the library (loading /opt/rocm's runtime first and torch afterwards leaves hipGetDevice failing).
+    import torch  # noqa: F401
+
     lib = C.CDLL(str(_LIB_PATH))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here means the .so is stale

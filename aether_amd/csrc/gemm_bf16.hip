@@ -108,10 +108,9 @@ extern "C" int aether_gemm_bf16(const void* A, int lda, const void* W, int ldw, 
     const int full = tiles / NCU * NCU, rest = tiles - full;
     int ks = (rest > 0 && rest <= NCU / 2) ? NCU / rest : 1;
     if (ks > nk / 4) ks = nk / 4;
-    if (splitk_ws == nullptr || full == 0 || (size_t)ks * rest * 256 * 256 * sizeof(float) > splitk_ws_bytes || (((uintptr_t)splitk_ws) & 15) ||
-        false)
+    if (ks < 2 || splitk_ws == nullptr || full == 0 || (((uintptr_t)splitk_ws) & 15) ||
+        (size_t)ks * rest * 256 * 256 * sizeof(float) > splitk_ws_bytes)
         ks = 1;
-    if (ks < 2) ks = 1;
     p.ntile_launch = (ks > 1) ? full : tiles;
 #define LAUNCH(E)                                                                                                        \
     do {                                                                                                                 \

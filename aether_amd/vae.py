@@ -58,14 +58,25 @@ class DiagonalGaussianDistribution:
 
 
 class _Conv:
-    """Packed convolution: weight bf16 [Cout_pad, K] with K ordered (dt, dh, dw, cin); bias fp32 [Cout_pad]."""
+    """Packed convolution: weight bf16 [Cout_pad, K], bias fp32 [Cout_pad].
+    K order of the implicit-GEMM convolutions (cin a multiple of 64): (dt, dh, channel block of 64, dw, 64 channels) — dw is the
+    innermost tap index, so three consecutive K steps of a workgroup read the SAME rows of the input volume shifted by one
+    voxel and the second and third hit L2 (the plain (dt, dh, dw, cin) order separates them by cin/64 K steps, i.e. by
+    cin/64 x 2 MB of other tiles' traffic per XCD).  The thin first convolutions (explicit im2col, `pad_k_to`) keep (dt, dh, dw, cin)."""
 
     def __init__(self, weight: torch.Tensor, bias: torch.Tensor, device, pad_k_to: Optional[int] = None):
         w = weight.detach().float()
         self.cout, self.cin = w.shape[0], w.shape[1]
         self.ksize = tuple(w.shape[2:])
-        perm = (0,) + tuple(range(2, w.dim())) + (1,)
-        w2 = w.permute(*perm).reshape(self.cout, -1)
+        self.blocked = pad_k_to is None and self.cin % 64 == 0 and len(self.ksize) >= 2
+        if self.blocked:
+            cb = self.cin // 64
+            w5 = w if w.dim() == 5 else w.unsqueeze(2)                       # [cout, cin, kt, kh, kw] (kt = 1 for conv2d)
+            kt, kh, kw = w5.shape[2:]
+            w2 = w5.reshape(self.cout, cb, 64, kt, kh, kw).permute(0, 3, 4, 1, 5, 2).reshape(self.cout, -1)   # (dt, dh, cb, dw, 64)
+        else:
+            perm = (0,) + tuple(range(2, w.dim())) + (1,)
+            w2 = w.permute(*perm).reshape(self.cout, -1)
         cout_pad = (self.cout + 31) // 32 * 32
         k_pad = pad_k_to or w2.shape[1]
         wp = torch.zeros(cout_pad, k_pad)
@@ -293,8 +304,9 @@ class AetherVAE:
         key = (kt, kh, kw, iH, iW, iC)
         t = self._taps.get(key)
         if t is None:
-            offs = [((dt * iH + dh) * iW + dw) * iC + cb * 64 for dt in range(kt) for dh in range(kh) for dw in range(kw)
-                    for cb in range(iC // 64)]
+            # same K order as _Conv packs the weights in: (dt, dh, channel block, dw)
+            offs = [((dt * iH + dh) * iW + dw) * iC + cb * 64 for dt in range(kt) for dh in range(kh) for cb in range(iC // 64)
+                    for dw in range(kw)]
             t = torch.tensor(offs, dtype=torch.int32, device=self.device)
             self._taps[key] = t
         return t

@@ -64,9 +64,15 @@ def main():
         out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
         R = rnd(M, N) if epi == ops.AETHER_EPI_BIAS_GATE_RES else None
         gate = rnd(1, 2 * N, dtype=torch.float32) if R is not None else None
-        for flags, use_ws in ((1, False), (1 | 4, False), (1 | 4, True), (1 | 8, True)):
-            kw = dict(R=R, gate_vid=gate[:, :N], gate_txt=gate[:, N:], rows_per_batch=M, n_text=226) if R is not None else {}
-            t = timeit(lambda: ops.gemm_bf16(A, W, bias, epi, out=out, flags=flags, splitk_ws=splitk_ws if use_ws else None, **kw))
+        variants = ((1, False), (1 | 4, False), (1 | 4, True), (1 | 8, True))
+        kw = dict(R=R, gate_vid=gate[:, :N], gate_txt=gate[:, N:], rows_per_batch=M, n_text=226) if R is not None else {}
+        times = {v: [] for v in variants}
+        for _ in range(3):                      # interleaved rounds (guide rule 24): median reported
+            for v in variants:
+                flags, use_ws = v
+                times[v].append(timeit(lambda: ops.gemm_bf16(A, W, bias, epi, out=out, flags=flags, splitk_ws=splitk_ws if use_ws else None, **kw)))
+        for (flags, use_ws), ts in times.items():
+            t = sorted(ts)[1]
             tf = 2.0 * M * N * K / t / 1e12
             res["results"].append({"kernel": name, "flags": flags, "tail_split_k": use_ws, "M": M, "N": N, "K": K, "ms": t * 1e3, "TFLOPs": tf,
                                    "frac_mfma_peak": tf / 2500.0})

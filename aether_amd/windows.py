@@ -98,6 +98,86 @@ def run_windows(call_window: Callable[[int], "object"], starts: Sequence[int], g
     return results
 
 
+def blend_and_merge_window_results(results: Sequence[WindowResult], *, height: int, width: int, align_pointmaps: bool = False,
+                                   smooth_camera: bool = True, smooth_method: str = "kalman"):
+    """The reference's sequential merge of overlapping windows (D:254-422), on the host in float64 like the reference:
+    window k is brought into the frame of everything merged so far — disparity by a least-squares scale over the overlap
+    (pixels with disparity > 0.1), camera poses by a similarity fitted on the overlapping cameras, focal lengths by their mean
+    ratio — and cross-faded linearly over the overlap (poses by slerp); finally every frame is back-projected to a world-space
+    point map.  Returns (rgb [N,H,W,3], disparity [N,H,W], poses [N,4,4], pointmaps [N,H,W,3]).
+    Reference quirks kept on purpose: windows' raymaps are decoded in place (geometry.raymap_to_poses); the aligned poses of
+    windows k >= 1 carry the similarity's scale in element [3,3] outside the overlap (apply_transformation on 4x4 inputs)."""
+    from . import geometry as G
+
+    sm = smooth_method if smooth_camera else "none"
+    first = results[0]
+    n_win = first.rgb.shape[0]
+    frame_shape = first.disparity.shape[1:]
+    rgb, disp = first.rgb, first.disparity
+    pm0 = G.postprocess_pointmap(first.disparity, first.raymap, vae_downsample_scale=8, ray_o_scale_inv=0.1,
+                                 smooth_camera=smooth_camera, smooth_method=sm)
+    poses = pm0["camera_pose"]
+    focals = (pm0["intrinsics"][:, 0, 0] + pm0["intrinsics"][:, 1, 1]) / 2
+    pointmaps = pm0["pointmap"] if align_pointmaps else None
+
+    for k in range(1, len(results)):
+        r, t0 = results[k], results[k].start
+        t1 = t0 + r.rgb.shape[0]
+        ov = results[k - 1].start + n_win - t0                              # frames shared with what is merged so far
+        fade = np.linspace(1, 0, ov)                                        # weight of the already merged frames
+
+        # disparity: scale onto the merged overlap, cross-fade
+        w_disp = r.disparity
+        cols = frame_shape[-1]
+        scale = G.compute_scale(w_disp[:ov].reshape(1, -1, cols), disp[-ov:].reshape(1, -1, cols),
+                                (w_disp[:ov].reshape(1, -1, cols) > 0.1))
+        w_disp = scale * w_disp
+        new_disp = np.ones((t1, *frame_shape))
+        new_disp[:t0] = disp[:t0]
+        new_disp[t0 + ov:] = w_disp[ov:]
+        new_disp[t0:t0 + ov] = disp[t0:t0 + ov] * fade[:, None, None] + w_disp[:ov] * (1 - fade[:, None, None])
+
+        # colour: cross-fade
+        new_rgb = np.ones((t1, *frame_shape, 3))
+        new_rgb[:t0] = rgb[:t0]
+        new_rgb[t0 + ov:] = r.rgb[ov:]
+        new_rgb[t0:t0 + ov] = rgb[t0:t0 + ov] * fade[:, None, None, None] + r.rgb[:ov] * (1 - fade[:, None, None, None])
+
+        # cameras: similarity from the overlapping cameras, slerp / lerp inside the overlap
+        w_poses, fov_x, fov_y = G.raymap_to_poses(r.raymap, ray_o_scale_inv=0.1)
+        aR, aT, aS = G.align_camera_extrinsics(w_poses[:ov], poses[-ov:])
+        w_aligned = G.apply_transformation(w_poses, aR, aT, aS)
+        new_poses = np.ones((t1, 4, 4))
+        new_poses[:t0] = poses[:t0]
+        new_poses[t0 + ov:] = w_aligned[ov:]
+        for t in range(ov):
+            new_poses[t0 + t] = G.interpolate_poses(poses[t0 + t], w_aligned[t], fade[t])
+
+        # focal lengths: mean ratio over the overlap, cross-fade
+        w_focals = G.focals_from_fov(w_poses.shape[0], r.disparity.shape[1], r.disparity.shape[2], fov_x, fov_y)
+        w_focals = (focals[-ov:] / w_focals[:ov]).mean() * w_focals
+        new_focals = np.ones((t1,))
+        new_focals[:t0] = focals[:t0]
+        new_focals[t0 + ov:] = w_focals[ov:]
+        new_focals[t0:t0 + ov] = focals[t0:t0 + ov] * fade + w_focals[:ov] * (1 - fade)
+
+        if align_pointmaps:
+            w_pm = G.postprocess_pointmap(new_disp[t0:], r.raymap, vae_downsample_scale=8, camera_pose=w_aligned, focal=w_focals,
+                                          ray_o_scale_inv=0.1, smooth_camera=smooth_camera, smooth_method=sm)["pointmap"]
+            new_pm = np.ones((t1, *frame_shape, 3))
+            new_pm[:t0] = pointmaps[:t0]
+            new_pm[t0 + ov:] = w_pm[ov:]
+            new_pm[t0:t0 + ov] = pointmaps[t0:t0 + ov] * fade[:, None, None, None] + w_pm[:ov] * (1 - fade[:, None, None, None])
+            pointmaps = new_pm
+        rgb, disp, poses, focals = new_rgb, new_disp, new_poses, new_focals
+
+    if not align_pointmaps:
+        pointmaps = np.stack([G.project(1 / np.clip(disp[i], 1e-8, 1e8),
+                                        np.array([[f, 0, 0.5 * width], [0, f, 0.5 * height], [0, 0, 1]]), poses[i])
+                              for i, f in enumerate(focals)])
+    return rgb, disp, poses, pointmaps
+
+
 def blend_rgb(results: Sequence[WindowResult], total_frames: int) -> np.ndarray:
     """Linear cross-fade of the RGB frames of overlapping windows (the colour part of D:254-422; the geometric part —
     disparity scale fitting, pose alignment — stays with the reference's numpy post-processing)."""

@@ -10,9 +10,10 @@ and window w runs on rank w mod N (aether_amd/windows.py); rank 0 blends and sav
 
 Extra, optional flags (the reference's flags are unchanged): --empty_prompt_embeds (a .pt with the cached T5 embedding
 of "" — the only thing the text encoder is ever used for, P:290-297), --synthetic_weights (seeded random weights, for
-smoke runs without checkpoints).  Geometry post-processing (disparity scale fitting, pose smoothing, point clouds,
-GLB export: D:254-521) is CPU numpy code outside this repo's scope; raw per-window outputs and the
-cross-faded RGB are written as .npz so the reference's own post-processing can consume them.
+smoke runs without checkpoints).  The window merge (disparity scale fitting, camera alignment, pose smoothing, point maps:
+D:254-422) runs on the host like the reference's (aether_amd/windows.py + aether_amd/geometry.py, pinned against the
+reference's own functions by tests/golden/blend.npz); merged rgb / disparity / poses / point maps are written as .npz + a
+preview frame — mp4 / GLB export (D:425-521: imageio, trimesh) is outside this repo's scope.
 """
 from __future__ import annotations
 
@@ -28,7 +29,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from aether.pipelines.aetherv1_pipeline_cogvideox import AetherV1PipelineCogVideoX  # noqa: E402
-from aether_amd.windows import blend_rgb, get_window_starts, run_windows  # noqa: E402
+from aether_amd.windows import WindowResult, blend_and_merge_window_results, get_window_starts, run_windows  # noqa: E402
 
 
 def seed_all(seed: int = 0) -> None:
@@ -136,6 +137,12 @@ def read_video(path: str) -> np.ndarray:
     return v.astype(np.float32) / 255.0 if v.dtype == np.uint8 else v.astype(np.float32)
 
 
+def merge(args, results):
+    """D:633-639 / D:436-449: merged (rgb, disparity, poses, pointmaps) of one or more windows."""
+    return blend_and_merge_window_results(results, height=args.height, width=args.width, align_pointmaps=args.align_pointmaps,
+                                          smooth_camera=args.smooth_camera, smooth_method=args.smooth_method)
+
+
 def save_output(args, **arrays):
     os.makedirs(args.output_dir, exist_ok=True)
     name = {"reconstruction": args.video, "prediction": args.image, "planning": args.image}[args.task] or "output"
@@ -193,12 +200,13 @@ def main(argv=None) -> None:
                               num_inference_steps=args.num_inference_steps, guidance_scale=args.guidance_scale,
                               use_dynamic_cfg=args.use_dynamic_cfg, generator=torch.Generator(device=device).manual_seed(args.seed),
                               return_dict=True, **common)
-            if not args.post_reconstruction:
-                save_output(args, rgb=output.rgb, disparity=output.disparity, raymap=output.raymap)
-            else:
-                recon = pipeline(task="reconstruction", video=output.rgb, num_inference_steps=4, guidance_scale=1.0, use_dynamic_cfg=False,
-                                 generator=torch.Generator(device=device).manual_seed(args.seed), **common)
-                save_output(args, rgb=output.rgb, disparity=recon.disparity, raymap=recon.raymap)
+            geo = output
+            if args.post_reconstruction:
+                geo = pipeline(task="reconstruction", video=output.rgb, num_inference_steps=4, guidance_scale=1.0, use_dynamic_cfg=False,
+                               generator=torch.Generator(device=device).manual_seed(args.seed), **common)
+            # like the reference's save_output (D:436-449): a single window goes through the same merge to get poses / point maps
+            _, _, poses, pointmaps = merge(args, [WindowResult(0, output.rgb, geo.disparity, geo.raymap.copy())])
+            save_output(args, rgb=output.rgb, disparity=geo.disparity, raymap=geo.raymap, poses=poses, pointmap=pointmaps)
     else:
         starts = get_window_starts(len(video), args.num_frames, args.sliding_window_stride)
 
@@ -210,8 +218,8 @@ def main(argv=None) -> None:
 
         results = run_windows(call_window, starts, gather_device=device)
         if results is not None:
-            save_output(args, rgb=blend_rgb(results, len(video)), window_starts=np.asarray(starts),
-                        window_disparity=np.stack([r.disparity for r in results]), window_raymap=np.stack([r.raymap for r in results]))
+            rgb, disparity, poses, pointmaps = merge(args, results)
+            save_output(args, rgb=rgb, disparity=disparity, poses=poses, pointmap=pointmaps, window_starts=np.asarray(starts))
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

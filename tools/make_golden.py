@@ -47,7 +47,83 @@ def main():
     rec_poses, fov_x, fov_y = U.raymap_to_poses(raymap.copy(), ray_o_scale_inv=0.1)
     np.savez_compressed(os.path.join(OUT, "raymap.npz"), poses=poses, K=K, raymap=raymap.astype(np.float32),
                         rec_poses=rec_poses, fov_x=np.asarray(fov_x), fov_y=np.asarray(fov_y))
+    make_blend_golden(U)
     print("wrote", os.listdir(OUT))
+
+
+def _reference_blend_function(U):
+    """The reference's blend_and_merge_window_results (scripts/demo.py:254-422) cannot be imported (imageio / rootutils are
+    absent and the module runs rootutils at import), so its SOURCE SEGMENT is read from /root/reference at generation time and
+    executed against the reference's own helper functions.  Nothing of it is stored in this repository but its outputs."""
+    import argparse
+    import ast
+    from typing import List, Tuple
+
+    import torch
+    src = open(os.path.join(REF, "scripts", "demo.py")).read()
+    node = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "blend_and_merge_window_results")
+    ns = dict(np=np, torch=torch, List=List, Tuple=Tuple, argparse=argparse, AetherV1PipelineOutput=object,
+              postprocess_pointmap=U.postprocess_pointmap, compute_scale=U.compute_scale, raymap_to_poses=U.raymap_to_poses,
+              align_camera_extrinsics=U.align_camera_extrinsics, apply_transformation=U.apply_transformation,
+              interpolate_poses=U.interpolate_poses, get_intrinsics=U.get_intrinsics, project=U.project)
+    exec(compile(ast.Module(body=[node], type_ignores=[]), "reference_demo_blend", "exec"), ns)
+    return ns["blend_and_merge_window_results"]
+
+
+def make_blend_golden(U):
+    """Three overlapping 9-frame windows (starts 0, 5, 10 of a 19-frame clip, 24x32 pixels, raymaps 3x4) whose cameras are
+    expressed in per-window frames (different origin, orientation and scale) and whose disparities carry per-window scales:
+    inputs + the reference's merged outputs for (align_pointmaps, smooth_camera, smooth_method) in
+    {(False, False, -), (True, False, -), (False, True, simple)}, plus unit-level outputs of the helpers."""
+    import types as _t
+    rng = np.random.default_rng(7)
+    H, W, F, starts, N = 24, 32, 9, [0, 5, 10], 19
+    t = np.linspace(0, 1, N)
+    world = np.tile(np.eye(4), (N, 1, 1))
+    ang = 0.5 * t
+    world[:, 0, 0], world[:, 0, 2], world[:, 2, 0], world[:, 2, 2] = np.cos(ang), np.sin(ang), -np.sin(ang), np.cos(ang)
+    world[:, 0, 3], world[:, 1, 3], world[:, 2, 3] = 0.5 * t, 0.05 * np.sin(6 * t), 1.2 * t
+    K = np.array([[28.0, 0, W / 2], [0, 28.0, H / 2], [0, 0, 1.0]])
+    yy, xx = np.mgrid[0:H, 0:W]
+    wins = []
+    for k, s0 in enumerate(starts):
+        rel = np.linalg.inv(world[s0]) @ world[s0:s0 + F]                 # each window predicts in its own first-frame system
+        rel[:, :3, 3] *= (1.0, 0.7, 1.3)[k]                                # ... and at its own scale
+        rel = rel + 1e-3 * rng.standard_normal(rel.shape) * np.array([1, 1, 1, 0])[:, None]   # prediction noise (rows 0-2)
+        raymap = U.camera_pose_to_raymap(camera_pose=rel.copy(), intrinsic=np.tile(K, (F, 1, 1)), H=H, W=W).astype(np.float32)
+        disp = np.stack([0.35 + 0.3 * np.sin(0.2 * xx + 0.3 * (s0 + f)) * np.cos(0.25 * yy) for f in range(F)])
+        disp = ((0.9, 1.2, 0.75)[k] * disp + 0.01 * rng.random(disp.shape)).clip(0.02, 1).astype(np.float32)
+        rgb = rng.random((F, H, W, 3), dtype=np.float32).astype(np.float16).astype(np.float32)   # stored as float16, exactly
+        wins.append((rgb, disp, raymap))
+    blend = _reference_blend_function(U)
+    out = {"starts": np.array(starts), "hw": np.array([H, W])}
+    for k, (rgb, disp, raymap) in enumerate(wins):
+        out[f"rgb_{k}"], out[f"disparity_{k}"], out[f"raymap_{k}"] = rgb.astype(np.float16), disp, raymap
+    for tag, (ap, sc, smeth) in {"plain": (False, False, "simple"), "aligned": (True, False, "simple"), "smooth": (False, True, "simple")}.items():
+        results = [_t.SimpleNamespace(rgb=r.copy(), disparity=d.copy(), raymap=m.copy()) for r, d, m in wins]
+        args = _t.SimpleNamespace(align_pointmaps=ap, smooth_camera=sc, smooth_method=smeth, width=W, height=H)
+        m_rgb, m_disp, m_poses, m_pm = blend(results, list(starts), args)
+        out[f"{tag}_disparity"], out[f"{tag}_poses"], out[f"{tag}_pointmaps"] = m_disp, m_poses, m_pm
+        if tag == "plain":
+            out["plain_rgb"] = m_rgb          # the colour cross-fade does not depend on the geometry options
+    # unit level
+    pm = U.postprocess_pointmap(wins[1][1].copy(), wins[1][2].copy(), vae_downsample_scale=8, ray_o_scale_inv=0.1)
+    out["unit_pointmap"], out["unit_pose"], out["unit_K"] = pm["pointmap"], pm["camera_pose"], pm["intrinsics"]
+    import torch
+    p_a, _, _ = U.raymap_to_poses(wins[1][2].copy(), ray_o_scale_inv=0.1)
+    p_b, _, _ = U.raymap_to_poses(wins[0][2].copy(), ray_o_scale_inv=0.1)
+    aR, aT, aS = U.align_camera_extrinsics(torch.from_numpy(p_a[:4]), torch.from_numpy(p_b[-4:]))
+    out["unit_align_R"], out["unit_align_T"], out["unit_align_s"] = aR.numpy(), aT.numpy(), np.array(float(aS))
+    out["unit_applied"] = U.apply_transformation(torch.from_numpy(p_a), aR, aT, aS, return_extri=True).numpy()
+    out["unit_interp"] = np.stack([U.interpolate_poses(p_a[0], p_b[3], wgt) for wgt in (0.0, 0.3, 1.0)])
+    out["unit_smooth_gauss"] = U.smooth_poses(p_a.copy(), 5, "gaussian")
+    out["unit_smooth_savgol"] = U.smooth_poses(p_a.copy(), 5, "savgol")
+    out["unit_scale"] = np.array(U.compute_scale(wins[1][1][:4].reshape(1, -1, W), wins[0][1][-4:].reshape(1, -1, W),
+                                                 wins[1][1][:4].reshape(1, -1, W) > 0.1))
+    out["unit_project"] = U.project(1 / np.clip(wins[0][1][2].astype(np.float64), 1e-8, 1e8), K, p_b[2])
+    # poses / scalars stay float64; images and point maps are stored as float32 (tests compare at 1e-5)
+    small = {k: (v.astype(np.float32) if isinstance(v, np.ndarray) and v.dtype == np.float64 and v.size > 1000 else v) for k, v in out.items()}
+    np.savez_compressed(os.path.join(OUT, "blend.npz"), **small)
 
 
 if __name__ == "__main__":

@@ -43,16 +43,19 @@ def get_rays(pose: np.ndarray, h: int, w: int, focal):
     T = pose.shape[0]
     K, focal = get_intrinsics(T, h, w, focal=focal)
     f = np.asarray(focal, dtype=np.float32).reshape(-1)             # a scalar focal broadcasts over the frames
+    if f.shape[0] == 1 and T > 1:
+        f = np.repeat(f, T)
     xs = (np.arange(w, dtype=np.float32) - np.float32(w * 0.5) + np.float32(0.5))
     ys = (np.arange(h, dtype=np.float32) - np.float32(h * 0.5) + np.float32(0.5))
-    gx, gy = np.meshgrid(xs, ys, indexing="xy")                     # [h, w]
-    dirs = np.stack([np.broadcast_to(gx.reshape(1, -1) / f[:, None], (T, h * w)),
-                     np.broadcast_to(gy.reshape(1, -1) / f[:, None], (T, h * w)),
-                     np.ones((T, h * w), np.float32)], axis=-1).astype(np.float32)     # [T, hw, 3]
     p32 = pose.astype(np.float32)
-    rays_d = dirs @ np.transpose(p32[:, :3, :3], (0, 2, 1))
-    rays_o = np.broadcast_to(p32[:, None, :3, 3], rays_d.shape)
-    return rays_o.reshape(T, h, w, 3).astype(np.float32), rays_d.reshape(T, h, w, 3).astype(np.float32), K
+    rays_d = np.empty((T, h, w, 3), np.float32)
+    for t in range(T):                                              # d = x·R[:,0] + y·R[:,1] + R[:,2], one frame at a time
+        R = p32[t, :3, :3]
+        np.multiply((xs / f[t])[None, :, None], R[None, None, :, 0], out=rays_d[t])
+        rays_d[t] += (ys / f[t])[:, None, None] * R[None, None, :, 1]
+        rays_d[t] += R[None, None, :, 2]
+    rays_o = np.broadcast_to(p32[:, None, None, :3, 3], rays_d.shape).copy()
+    return rays_o, rays_d, K
 
 
 def raymap_to_poses(raymap: np.ndarray, camera_pose: Optional[np.ndarray] = None, ray_o_scale_inv: float = 1.0,

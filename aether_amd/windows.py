@@ -113,68 +113,68 @@ def blend_and_merge_window_results(results: Sequence[WindowResult], *, height: i
     first = results[0]
     n_win = first.rgb.shape[0]
     frame_shape = first.disparity.shape[1:]
-    rgb, disp = first.rgb, first.disparity
+    total = results[-1].start + results[-1].rgb.shape[0]
+    # The reference re-allocates (np.ones) and re-copies every merged array for each window (O(windows²) traffic: ~8 GB of
+    # float64 copies for a 192-frame clip); the same values are written here into arrays allocated once at the final length.
+    rgb = np.empty((total, *frame_shape, 3))            # every element is written below
+    disp = np.empty((total, *frame_shape))
+    poses = np.empty((total, 4, 4))
+    focals = np.empty((total,))
+    pointmaps = np.empty((total, *frame_shape, 3)) if align_pointmaps else None
+    rgb[:n_win], disp[:n_win] = first.rgb, first.disparity
     pm0 = G.postprocess_pointmap(first.disparity, first.raymap, vae_downsample_scale=8, ray_o_scale_inv=0.1,
                                  smooth_camera=smooth_camera, smooth_method=sm)
-    poses = pm0["camera_pose"]
-    focals = (pm0["intrinsics"][:, 0, 0] + pm0["intrinsics"][:, 1, 1]) / 2
-    pointmaps = pm0["pointmap"] if align_pointmaps else None
+    poses[:n_win] = pm0["camera_pose"]
+    focals[:n_win] = (pm0["intrinsics"][:, 0, 0] + pm0["intrinsics"][:, 1, 1]) / 2
+    if align_pointmaps:
+        pointmaps[:n_win] = pm0["pointmap"]
+    end = n_win                                                             # frames merged so far
 
     for k in range(1, len(results)):
         r, t0 = results[k], results[k].start
         t1 = t0 + r.rgb.shape[0]
         ov = results[k - 1].start + n_win - t0                              # frames shared with what is merged so far
+        assert end == t0 + ov
         fade = np.linspace(1, 0, ov)                                        # weight of the already merged frames
 
         # disparity: scale onto the merged overlap, cross-fade
-        w_disp = r.disparity
         cols = frame_shape[-1]
-        scale = G.compute_scale(w_disp[:ov].reshape(1, -1, cols), disp[-ov:].reshape(1, -1, cols),
-                                (w_disp[:ov].reshape(1, -1, cols) > 0.1))
-        w_disp = scale * w_disp
-        new_disp = np.ones((t1, *frame_shape))
-        new_disp[:t0] = disp[:t0]
-        new_disp[t0 + ov:] = w_disp[ov:]
-        new_disp[t0:t0 + ov] = disp[t0:t0 + ov] * fade[:, None, None] + w_disp[:ov] * (1 - fade[:, None, None])
+        scale = G.compute_scale(r.disparity[:ov].reshape(1, -1, cols), disp[t0:end].reshape(1, -1, cols),
+                                (r.disparity[:ov].reshape(1, -1, cols) > 0.1))
+        w_disp = scale * r.disparity
+        disp[t0:end] = disp[t0:end] * fade[:, None, None] + w_disp[:ov] * (1 - fade[:, None, None])
+        disp[end:t1] = w_disp[ov:]
 
         # colour: cross-fade
-        new_rgb = np.ones((t1, *frame_shape, 3))
-        new_rgb[:t0] = rgb[:t0]
-        new_rgb[t0 + ov:] = r.rgb[ov:]
-        new_rgb[t0:t0 + ov] = rgb[t0:t0 + ov] * fade[:, None, None, None] + r.rgb[:ov] * (1 - fade[:, None, None, None])
+        rgb[t0:end] = rgb[t0:end] * fade[:, None, None, None] + r.rgb[:ov] * (1 - fade[:, None, None, None])
+        rgb[end:t1] = r.rgb[ov:]
 
         # cameras: similarity from the overlapping cameras, slerp / lerp inside the overlap
         w_poses, fov_x, fov_y = G.raymap_to_poses(r.raymap, ray_o_scale_inv=0.1)
-        aR, aT, aS = G.align_camera_extrinsics(w_poses[:ov], poses[-ov:])
+        aR, aT, aS = G.align_camera_extrinsics(w_poses[:ov], poses[t0:end])
         w_aligned = G.apply_transformation(w_poses, aR, aT, aS)
-        new_poses = np.ones((t1, 4, 4))
-        new_poses[:t0] = poses[:t0]
-        new_poses[t0 + ov:] = w_aligned[ov:]
         for t in range(ov):
-            new_poses[t0 + t] = G.interpolate_poses(poses[t0 + t], w_aligned[t], fade[t])
+            poses[t0 + t] = G.interpolate_poses(poses[t0 + t], w_aligned[t], fade[t])
+        poses[end:t1] = w_aligned[ov:]
 
         # focal lengths: mean ratio over the overlap, cross-fade
         w_focals = G.focals_from_fov(w_poses.shape[0], r.disparity.shape[1], r.disparity.shape[2], fov_x, fov_y)
-        w_focals = (focals[-ov:] / w_focals[:ov]).mean() * w_focals
-        new_focals = np.ones((t1,))
-        new_focals[:t0] = focals[:t0]
-        new_focals[t0 + ov:] = w_focals[ov:]
-        new_focals[t0:t0 + ov] = focals[t0:t0 + ov] * fade + w_focals[:ov] * (1 - fade)
+        w_focals = (focals[t0:end] / w_focals[:ov]).mean() * w_focals
+        focals[t0:end] = focals[t0:end] * fade + w_focals[:ov] * (1 - fade)
+        focals[end:t1] = w_focals[ov:]
 
         if align_pointmaps:
-            w_pm = G.postprocess_pointmap(new_disp[t0:], r.raymap, vae_downsample_scale=8, camera_pose=w_aligned, focal=w_focals,
+            w_pm = G.postprocess_pointmap(disp[t0:t1], r.raymap, vae_downsample_scale=8, camera_pose=w_aligned, focal=w_focals,
                                           ray_o_scale_inv=0.1, smooth_camera=smooth_camera, smooth_method=sm)["pointmap"]
-            new_pm = np.ones((t1, *frame_shape, 3))
-            new_pm[:t0] = pointmaps[:t0]
-            new_pm[t0 + ov:] = w_pm[ov:]
-            new_pm[t0:t0 + ov] = pointmaps[t0:t0 + ov] * fade[:, None, None, None] + w_pm[:ov] * (1 - fade[:, None, None, None])
-            pointmaps = new_pm
-        rgb, disp, poses, focals = new_rgb, new_disp, new_poses, new_focals
+            pointmaps[t0:end] = pointmaps[t0:end] * fade[:, None, None, None] + w_pm[:ov] * (1 - fade[:, None, None, None])
+            pointmaps[end:t1] = w_pm[ov:]
+        end = t1
 
     if not align_pointmaps:
-        pointmaps = np.stack([G.project(1 / np.clip(disp[i], 1e-8, 1e8),
-                                        np.array([[f, 0, 0.5 * width], [0, f, 0.5 * height], [0, 0, 1]]), poses[i])
-                              for i, f in enumerate(focals)])
+        pointmaps = np.empty((total, *frame_shape, 3))
+        for i, f in enumerate(focals):
+            pointmaps[i] = G.project(1 / np.clip(disp[i], 1e-8, 1e8), np.array([[f, 0, 0.5 * width], [0, f, 0.5 * height], [0, 0, 1]]),
+                                     poses[i])
     return rgb, disp, poses, pointmaps
 
 

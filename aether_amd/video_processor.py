@@ -63,9 +63,10 @@ class VideoProcessor:
         outs = []
         for b in range(video.shape[0]):
             frames = (video[b].permute(1, 0, 2, 3) / 2 + 0.5).clamp(0, 1)
-            outs.append(frames.cpu().permute(0, 2, 3, 1).float().numpy() if output_type == "np" else frames)
+            # permute + bf16->fp32 (exact) on the device, then ONE contiguous D2H copy (upstream converts on the host after the copy)
+            outs.append(frames.permute(0, 2, 3, 1).float().contiguous().cpu().numpy() if output_type == "np" else frames)
         if output_type == "np":
-            return np.stack(outs)
+            return outs[0][None] if len(outs) == 1 else np.stack(outs)
         if output_type == "pt":
             return torch.stack(outs)
         raise ValueError(f"{output_type} does not exist. Please choose one of ['np', 'pt']")

@@ -25,7 +25,7 @@ import PIL.Image
 import torch
 from einops import rearrange
 
-from ..preprocess import center_crop_frames
+from ..preprocess import center_crop_frames, crop_window
 from ..rope import resize_crop_region_for_grid, rotary_tables_3d
 from ..scheduler import CogVideoXDPMScheduler, randn_tensor
 from ..video_processor import VideoProcessor
@@ -279,6 +279,23 @@ class AetherV1PipelineCogVideoX(_PipelineBase):
         frames = center_crop_frames(frames, height, width)
         return self.video_processor.preprocess(frames, height, width)
 
+    def _preprocess_frames_on_device(self, frames, height, width, dev):
+        """Same values as `_preprocess_image(...).to(dev, bfloat16)` for an [N,H,W,C] / [H,W,C] uint8 or float32 array whose
+        centred crop window (preprocess_utils.py:4-39) lies inside the frame and already has the target size: the cropped VIEW
+        is uploaded once and /255, 2x-1 (fp32, the same two IEEE operations as the host path), NHWC->NCHW and the bf16 rounding
+        run on the device instead of as four host passes over the clip.  Returns None when the fast path does not apply."""
+        if isinstance(frames, torch.Tensor) or frames.dtype not in (np.uint8, np.float32) or frames.ndim not in (3, 4):
+            return None
+        arr = frames[None] if frames.ndim == 3 else frames
+        top, left, ch, cw = crop_window(arr.shape[1], arr.shape[2], height, width)
+        if (ch, cw) != (height, width) or top < 0 or left < 0 or top + ch > arr.shape[1] or left + cw > arr.shape[2]:
+            return None
+        t = torch.from_numpy(arr[:, top:top + ch, left:left + cw]).to(dev)
+        if t.dtype == torch.uint8:
+            t = t.to(torch.float32) / 255.0
+        t = 2.0 * t.permute(0, 3, 1, 2) - 1.0
+        return t.to(torch.bfloat16).contiguous()
+
     def preprocess_inputs(self, image, goal, video, raymap, height, width, num_frames):
         dev = self._execution_device
 
@@ -288,6 +305,9 @@ class AetherV1PipelineCogVideoX(_PipelineBase):
             if pil_ok(x):
                 y = self.video_processor.preprocess(x, height, width, resize_mode="crop")
             else:
+                y = self._preprocess_frames_on_device(x, height, width, dev)
+                if y is not None:
+                    return y
                 y = self._preprocess_image(x, height, width)
             return y.to(device=dev, dtype=torch.bfloat16)
 

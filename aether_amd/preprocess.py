@@ -7,7 +7,7 @@ from typing import List, Sequence
 import numpy as np
 
 
-def _crop_window(h: int, w: int, target_h: int, target_w: int):
+def crop_window(h: int, w: int, target_h: int, target_w: int):
     """(top, left, crop_h, crop_w) of the largest centred window with the target aspect ratio."""
     if target_h / target_w > h / w:          # source too wide: trim left/right
         cw = int(h / target_h * target_w)
@@ -19,7 +19,7 @@ def _crop_window(h: int, w: int, target_h: int, target_w: int):
 def center_crop_frames(frames: Sequence[np.ndarray], target_h: int, target_w: int) -> List[np.ndarray]:
     out = []
     for img in frames:
-        top, left, ch, cw = _crop_window(img.shape[0], img.shape[1], target_h, target_w)
+        top, left, ch, cw = crop_window(img.shape[0], img.shape[1], target_h, target_w)
         canvas = np.zeros((ch, cw, *img.shape[2:]), dtype=img.dtype)
         # clip the window to the image (the reference zero-fills whatever falls outside)
         y0, x0 = max(top, 0), max(left, 0)

@@ -110,3 +110,21 @@ def test_check_inputs_messages(parts):
         assert str(e.value) == msg, (kw.keys(), str(e.value))
     with pytest.raises(ValueError, match="`raymap` shape is not correct"):
         pipe(task="prediction", image=img, raymap=np.zeros((F, 6, 4, 4), np.float32), height=H, width=W, num_frames=F)
+
+
+def test_device_preprocess_fast_path_matches_host_path(parts):
+    """uint8 / float32 clips whose centred crop already has the target size take the upload-then-normalise path; it must
+    give the bits of the generic host path (crop copy, stack, 2x-1, bf16), and decline everything else."""
+    pipe = _pipe(parts)
+    g = np.random.default_rng(11)
+    dev = torch.device("cpu")
+    for arr in (_video(), (g.random((F, H, W, 3)) * 255).astype(np.uint8), _video()[0],
+                g.random((5, H, W + 40, 3), dtype=np.float32),                 # wider source: window at left = 20
+                (g.random((3, H + 16, W, 3)) * 255).astype(np.uint8)):         # taller source: window at top = 8
+        fast = pipe._preprocess_frames_on_device(arr, H, W, dev)
+        assert fast is not None and fast.dtype == torch.bfloat16 and fast.is_contiguous()
+        slow = pipe._preprocess_image(arr, H, W).to(torch.bfloat16)
+        assert fast.shape == slow.shape and torch.equal(fast, slow)
+    assert pipe._preprocess_frames_on_device(g.random((2, H // 2, W // 2, 3), dtype=np.float32), H, W, dev) is None   # needs a resize
+    assert pipe._preprocess_frames_on_device(g.random((2, H, W, 3)), H, W, dev) is None                                # float64
+    assert pipe._preprocess_frames_on_device(torch.zeros(2, H, W, 3), H, W, dev) is None

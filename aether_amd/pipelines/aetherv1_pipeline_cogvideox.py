@@ -380,6 +380,35 @@ class AetherV1PipelineCogVideoX(_PipelineBase):
         return latents, condition_latents
 
     # -------------------------------------------------------------------------------------------------
+    # ---- two-rank classifier-free-guidance split (not in the reference, which is single-process) -----------
+    _cfg_group = None
+    _cfg_rank = 0
+
+    def enable_cfg_parallel(self, group=None) -> None:
+        """Prediction / planning run the transformer on a batch of two (unconditional, conditional: P:832-859).  With a
+        two-rank process group, rank 0 of the group evaluates the unconditional branch and rank 1 the conditional one, each at
+        batch 1; the bf16 `noise_pred` halves (6.65 MB at 41x480x720) are exchanged with one all-gather per step and BOTH ranks
+        then perform the identical guidance combination and scheduler step, so the latents stay replicated without a
+        broadcast.  After the loop rank 0 decodes the rgb latents and rank 1 the disparity latents (one more all-gather).
+        Callers must give both ranks the same inputs and a generator with the same seed.  No effect when guidance is off."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("enable_cfg_parallel needs an initialised torch.distributed process group")
+        if dist.get_world_size(group) != 2:
+            raise ValueError(f"cfg-parallel needs a process group of exactly two ranks, got {dist.get_world_size(group)}")
+        self._cfg_group = group if group is not None else dist.group.WORLD
+        self._cfg_rank = dist.get_rank(group)
+
+    def disable_cfg_parallel(self) -> None:
+        self._cfg_group, self._cfg_rank = None, 0
+
+    def _gather_pair(self, x: torch.Tensor) -> torch.Tensor:
+        """[1, ...] on each rank of the pair -> [2, ...] in group-rank order on both."""
+        import torch.distributed as dist
+        parts = [torch.empty_like(x, memory_format=torch.contiguous_format) for _ in range(2)]
+        dist.all_gather(parts, x.contiguous(), group=self._cfg_group)
+        return torch.cat(parts)
+
     def _unconditional(self, task: str, condition_latents: torch.Tensor, goal) -> torch.Tensor:
         """Classifier-free branch: drop the observed RGB latents (P:839-855)."""
         nz = self.vae.config.latent_channels
@@ -442,7 +471,10 @@ class AetherV1PipelineCogVideoX(_PipelineBase):
         dpm = isinstance(self.scheduler, CogVideoXDPMScheduler) or type(self.scheduler).__name__ == "CogVideoXDPMScheduler"
         n_warm = max(len(timesteps) - num_inference_steps * self.scheduler.order, 0)
         latent_condition = self._unconditional(task, condition_latents, goal) if do_cfg else condition_latents
-        text = prompt_embeds.repeat(2 if do_cfg else 1, 1, 1)
+        split = do_cfg and self._cfg_group is not None            # this rank evaluates one guidance branch at batch 1
+        if split:
+            latent_condition = latent_condition[self._cfg_rank:self._cfg_rank + 1]
+        text = prompt_embeds.repeat(2 if (do_cfg and not split) else 1, 1, 1)
 
         with self.progress_bar(total=num_inference_steps) as bar:
             old_x0 = None
@@ -450,12 +482,14 @@ class AetherV1PipelineCogVideoX(_PipelineBase):
                 if self.interrupt:
                     continue
                 self._current_timestep = t
-                model_in = torch.cat([latents] * 2) if do_cfg else latents
+                model_in = torch.cat([latents] * 2) if (do_cfg and not split) else latents
                 model_in = self.scheduler.scale_model_input(model_in, t)
                 model_in = torch.cat([model_in, latent_condition], dim=2)                        # P:857-859 -> 96 channels
                 noise_pred = self.transformer(hidden_states=model_in, encoder_hidden_states=text,
                                               timestep=t.expand(model_in.shape[0]), ofs=ofs_emb, image_rotary_emb=rope,
                                               attention_kwargs=attention_kwargs, return_dict=False)[0]
+                if split:
+                    noise_pred = self._gather_pair(noise_pred)                                   # (unconditional, conditional)
                 noise_pred = noise_pred.float()
                 if use_dynamic_cfg:
                     # the reference feeds the raw timestep value (999 ... 19) here, literally (P:880-893)
@@ -476,8 +510,13 @@ class AetherV1PipelineCogVideoX(_PipelineBase):
 
         nz = self.vae.config.latent_channels
         rgb_latents, disparity_latents, camera_latents = latents[:, :, :nz], latents[:, :, nz:2 * nz], latents[:, :, 2 * nz:]
-        rgb_video = self.video_processor.postprocess_video(video=self.decode_latents(rgb_latents), output_type="np")
-        disparity_video = self.decode_latents(disparity_latents).mean(dim=1, keepdim=False)
+        if split:
+            rgb_decoded, disparity_decoded = self._gather_pair(
+                self.decode_latents(rgb_latents if self._cfg_rank == 0 else disparity_latents)).split(1)
+        else:
+            rgb_decoded, disparity_decoded = self.decode_latents(rgb_latents), self.decode_latents(disparity_latents)
+        rgb_video = self.video_processor.postprocess_video(video=rgb_decoded, output_type="np")
+        disparity_video = disparity_decoded.mean(dim=1, keepdim=False)
         disparity_video = torch.square(disparity_video * 0.5 + 0.5).float().cpu().numpy()
         raymap_out = rearrange(camera_latents, "b t (n c) h w -> b (n t) c h w", n=4)[:, -rgb_video.shape[1]:, :, :]
         raymap_out = raymap_out.float().cpu().numpy()

@@ -195,11 +195,20 @@ def main(argv=None) -> None:
 
     common = dict(height=args.height, width=args.width, num_frames=args.num_frames, fps=args.fps)
     if args.task != "reconstruction":
-        if rank == 0:   # a single clip: replicas only
+        # A single clip.  With two or more ranks the two guidance branches run on ranks 0 and 1:
+        # one all-gather of the bf16 noise prediction per step; further ranks have nothing to do.
+        pair = None
+        if world >= 2 and args.guidance_scale > 1.0:
+            import torch.distributed as dist
+            pair = dist.new_group([0, 1])                 # collective over all ranks
+            if rank < 2:
+                pipeline.enable_cfg_parallel(pair)
+        if rank == 0 or (pair is not None and rank == 1):
             output = pipeline(task=args.task, image=image, video=None, goal=goal, raymap=raymap,
                               num_inference_steps=args.num_inference_steps, guidance_scale=args.guidance_scale,
                               use_dynamic_cfg=args.use_dynamic_cfg, generator=torch.Generator(device=device).manual_seed(args.seed),
                               return_dict=True, **common)
+        if rank == 0:
             geo = output
             if args.post_reconstruction:
                 geo = pipeline(task="reconstruction", video=output.rgb, num_inference_steps=4, guidance_scale=1.0, use_dynamic_cfg=False,

@@ -128,3 +128,61 @@ def test_device_preprocess_fast_path_matches_host_path(parts):
     assert pipe._preprocess_frames_on_device(g.random((2, H // 2, W // 2, 3), dtype=np.float32), H, W, dev) is None   # needs a resize
     assert pipe._preprocess_frames_on_device(g.random((2, H, W, 3)), H, W, dev) is None                                # float64
     assert pipe._preprocess_frames_on_device(torch.zeros(2, H, W, 3), H, W, dev) is None
+
+
+_CFG_WORKER = '''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import test_pipeline_cpu as T
+torch.set_num_threads(2)
+world = int(os.environ.get("WORLD_SIZE", "1"))
+if world > 1:
+    dist.init_process_group("gloo")
+parts = T.parts.__wrapped__() if hasattr(T.parts, "__wrapped__") else T.parts.__pytest_wrapped__.obj()
+pipe = T._pipe(parts)
+if world > 1:
+    pipe.enable_cfg_parallel()
+img, goal = T._video()[0], T._video()[-1]
+out = {}
+for task, kw in (("prediction", dict(image=img)), ("planning", dict(image=img, goal=goal))):
+    r = pipe(task=task, height=T.H, width=T.W, num_frames=T.F, num_inference_steps=3, use_dynamic_cfg=True,
+             generator=torch.Generator().manual_seed(5), **kw)
+    out[task + "_rgb"], out[task + "_disparity"], out[task + "_raymap"] = r.rgb, r.disparity, r.raymap
+# guidance off: the pair must not communicate (rank 1 may not even make the call)
+if world == 1 or dist.get_rank() == 0:
+    r = pipe(task="reconstruction", video=T._video(), height=T.H, width=T.W, num_frames=T.F, num_inference_steps=2,
+             generator=torch.Generator().manual_seed(5))
+    out["rec_rgb"] = r.rgb
+np.savez(%(out)r + (".%%d" %% (dist.get_rank() if world > 1 else 0)), **out)
+if world > 1:
+    dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_cfg_parallel_two_ranks_gloo(tmp_path):
+    """SURVEY.md §8e: one guidance branch per rank, exchanged every step.  Both ranks must hold the same outputs bit for bit,
+    and they must agree with the single-process batch-of-two run (to bf16 rounding: a batch-1 and a batch-2 matmul may block
+    their reductions differently)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for world in (1, 2):
+        out = str(tmp_path / f"w{world}")
+        script = tmp_path / f"cfg_worker{world}.py"
+        script.write_text(_CFG_WORKER % dict(root=root, out=out))
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+        cmd = ([sys.executable, str(script)] if world == 1 else
+               [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                "--master-port", "29519", str(script)])
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[world] = [np.load(f"{out}.{k}.npz") for k in range(world)]
+    single, (r0, r1) = outs[1][0], outs[2]
+    for k in r1.files:
+        assert np.array_equal(r0[k], r1[k]), f"ranks disagree on {k}"
+    for k in single.files:
+        a, b = single[k].astype(np.float64), r0[k].astype(np.float64)
+        assert a.shape == b.shape and np.abs(a - b).max() <= 2e-2 * max(1.0, np.abs(a).max()), (k, np.abs(a - b).max())
+    assert np.array_equal(single["rec_rgb"], r0["rec_rgb"])

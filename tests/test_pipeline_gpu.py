@@ -136,3 +136,68 @@ def test_device_generator_runs(world):
     a = _native(world, "reconstruction", video=video, generator=torch.Generator(device=world.cuda).manual_seed(42))
     b = _native(world, "reconstruction", video=video, generator=torch.Generator(device=world.cuda).manual_seed(42))
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+_CFG_WORKER = '''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import test_pipeline_gpu as T
+from aether.pipelines.aetherv1_pipeline_cogvideox import AetherV1PipelineCogVideoX
+from aether_amd.scheduler import CogVideoXDPMScheduler
+from aether_amd.transformer import AetherTransformer3D
+from aether_amd.vae import AetherVAE
+from oracle.dit import DitConfig, OracleTransformer3D, init_random_ as init_dit     # weights only (seeded random init)
+from oracle.vae import OracleVAE, VaeConfig, init_random_ as init_vae
+world = int(os.environ.get("WORLD_SIZE", "1"))
+if world > 1:
+    dist.init_process_group("gloo")          # both ranks share the box's single GPU; RCCL needs one device per rank
+cuda = torch.device("cuda", 0)
+tkw = dict(num_attention_heads=8, num_layers=2, text_embed_dim=128, time_embed_dim=64, max_text_seq_length=20,
+           sample_width=T.W // 8, sample_height=T.H // 8, sample_frames=T.F)
+vkw = dict(block_out_channels=(64, 128, 128, 128), layers_per_block=1, sample_height=T.H, sample_width=T.W)
+dsd = {k: v.to(torch.bfloat16) for k, v in init_dit(OracleTransformer3D(DitConfig(**tkw)), seed=1).state_dict().items()}
+vsd = {k: v.to(torch.bfloat16) for k, v in init_vae(OracleVAE(VaeConfig(**vkw)), seed=2).state_dict().items()}
+ndit = AetherTransformer3D(tkw, device=cuda).load_state_dict(dsd)
+nvae = AetherVAE(vkw, device=cuda).load_state_dict(vsd)
+nvae.enable_tiling(); nvae.enable_slicing()
+prompt = (torch.randn(1, 20, 128, generator=torch.Generator().manual_seed(0)) * 0.1).to(torch.bfloat16)
+pipe = AetherV1PipelineCogVideoX(tokenizer=None, text_encoder=None, vae=nvae, scheduler=CogVideoXDPMScheduler(), transformer=ndit,
+                                 empty_prompt_embeds=prompt)
+pipe.set_progress_bar_config(disable=True)
+if world > 1:
+    pipe.enable_cfg_parallel()
+out = {}
+for task, kw in (("prediction", dict(image=T._video()[0])), ("planning", dict(image=T._video()[0], goal=T._video()[-1]))):
+    r = pipe(task=task, height=T.H, width=T.W, num_frames=T.F, num_inference_steps=3, use_dynamic_cfg=True,
+             generator=torch.Generator(device=cuda).manual_seed(5), **kw)
+    out[task + "_rgb"], out[task + "_disparity"], out[task + "_raymap"] = r.rgb, r.disparity, r.raymap
+np.savez(%(out)r + (".%%d" %% (dist.get_rank() if world > 1 else 0)), **out)
+if world > 1:
+    dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_cfg_parallel_native_two_ranks(cuda, hip_lib, tmp_path):
+    """The two-rank guidance split (SURVEY.md §8e) through the HIP transformer and VAE: two processes on this box's GPU
+    exchanging over gloo.  Ranks must agree bit for bit; against the single-process batch-of-two run the difference must stay
+    at bf16 rounding level (batch 1 and batch 2 tile the same GEMMs differently, e.g. which tiles take the split-K tail)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for world in (1, 2):
+        out = str(tmp_path / f"w{world}")
+        script = tmp_path / f"cfg_worker{world}.py"
+        script.write_text(_CFG_WORKER % dict(root=root, out=out))
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
+        cmd = ([sys.executable, str(script)] if world == 1 else
+               [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                "--master-port", "29523", str(script)])
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[world] = [np.load(f"{out}.{k}.npz") for k in range(world)]
+    single, (r0, r1) = outs[1][0], outs[2]
+    for k in r0.files:
+        assert np.array_equal(r0[k], r1[k]), f"ranks disagree on {k}"
+        assert _rel(r0[k], single[k].astype(np.float64)) < 2e-2, (k, _rel(r0[k], single[k].astype(np.float64)))

@@ -53,6 +53,7 @@ SIGNATURES = {
     "aether_groupnorm_stats": (_i, [_vp, _i, _i, _i, _i, _f, _fp, _fp, _fp, _i, _fp, _fp, _vp]),
     "aether_spatial_cond": (_i, [_vp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _vp]),
     "aether_groupnorm_apply": (_i, [_vp, _i, _i, _i, _i, _i, _fp, _i, _vp, _i, _i, _i, _i, _i, _i, _fp, _i, _i, _i, C.POINTER(C.c_int), _vp]),
+    "aether_causal_front": (_i, [_vp, _i, _i, C.c_long, _vp, _vp, _vp]),
     "aether_resample_pad": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "aether_dit_create": (_vp, [C.POINTER(AetherDitConfig)]),
     "aether_dit_destroy": (None, [_vp]),

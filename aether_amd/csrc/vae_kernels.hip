@@ -232,6 +232,33 @@ extern "C" int aether_im2col_first(const void* x, long sC, long sT, long sH, lon
     return aether_check_launch("im2col_first");
 }
 
+namespace aether {
+// grid (pieces, 4, NB): y = 0,1 -> front frame y of vol; y = 2,3 -> frame y-2 of the cache handed to the next chunk.
+__global__ __launch_bounds__(256) void causal_front_kernel(uint4* __restrict__ vol, int Tp, long fvec, const uint4* __restrict__ prev,
+                                                           uint4* __restrict__ next) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= fvec) return;
+    const int nb = blockIdx.z, y = blockIdx.y;
+    uint4* v = vol + (size_t)nb * Tp * fvec;
+    int frame = (y < 2) ? y : Tp - 2 + (y - 2);                     // frame of the padded volume this output equals
+    uint4 val;
+    if (frame >= 2) val = v[(size_t)frame * fvec + i];                // an interior frame (only reached for the cache)
+    else val = prev ? prev[((size_t)nb * 2 + frame) * fvec + i] : v[(size_t)2 * fvec + i];
+    if (y < 2) v[(size_t)y * fvec + i] = val;
+    else next[((size_t)nb * 2 + (y - 2)) * fvec + i] = val;
+}
+}  // namespace aether
+
+extern "C" int aether_causal_front(void* vol, int NB, int Tp, long frame_elems, const void* prev, void* next, void* stream) {
+    if (!vol || !next || NB <= 0 || Tp < 3 || frame_elems <= 0 || (frame_elems % 8) != 0)
+        return aether_set_error(AETHER_ERR_ARG, "causal_front: bad arguments (Tp >= 3, frame size a multiple of 8 elements)");
+    if ((((uintptr_t)vol | (uintptr_t)prev | (uintptr_t)next) & 15) != 0) return aether_set_error(AETHER_ERR_ALIGN, "causal_front: pointers must be 16-byte aligned");
+    const long fvec = frame_elems / 8;
+    hipLaunchKernelGGL(causal_front_kernel, dim3((unsigned)((fvec + 255) / 256), 4, NB), dim3(256), 0, AE_STREAM, (uint4*)vol, Tp, fvec,
+                       (const uint4*)prev, (uint4*)next);
+    return aether_check_launch("causal_front");
+}
+
 extern "C" int aether_resample_pad(const void* x, int NB, int T, int H, int W, int C, int mode, void* y, int oT, int oH, int oW,
                                    int pt, int ph, int pw, void* stream) {
     if (!x || !y || C % 8 != 0 || mode < 0 || mode > 3) return aether_set_error(AETHER_ERR_ARG, "resample_pad: bad arguments");

@@ -1,9 +1,9 @@
 // GroupNorm / SpatialNorm3D of the CogVideoX VAE (diffusers nn.GroupNorm(32, C, eps=1e-6) and CogVideoXSpatialNorm3D,
 // reached from aether/pipelines/aetherv1_pipeline_cogvideox.py:557-618 and P:931,936).  HBM-bound by design:
 //   1. groupnorm_partial_kernel   one streaming read of x [NB, V, C]: per-block, per-channel (sum, sum of squares)
-//   2. groupnorm_finalize_kernel  merges block partials + the channels of a group in double precision (parallel-variance
-//                                 formula, fixed order -> deterministic) and folds gamma/beta into a per-channel
-//                                 affine table  y = x*scale[c] + shift[c]
+//   2. groupnorm_finalize_kernel  adds block partials + the channels of a group in double precision (fixed order ->
+//                                 deterministic) and folds gamma/beta into a per-channel affine table
+//                                 y = x*scale[c] + shift[c]
 //   3. spatial_cond_kernel        SpatialNorm3D only: conv_y / conv_b (1x1x1, 16 -> C) evaluated ONCE at latent
 //                                 resolution; nearest up-sampling commutes with a 1x1x1 convolution, so the full-
 //                                 resolution pass only gathers 2 x 8 floats per 16-byte piece
@@ -14,82 +14,86 @@
 
 namespace aether {
 
-__global__ __launch_bounds__(256) void groupnorm_partial_kernel(const unsigned short* __restrict__ x, int V, int C, int vpb,
-                                                                float* __restrict__ part) {
-    __shared__ float red[2][256][8];
+// Streaming read at HBM rate needs many loads in flight: 1024 threads per workgroup, four independent 16-byte loads per thread
+// and iteration (256 workgroups x 1024 x 64 B = 16 MiB outstanding on the whole chip).
+constexpr int GN_PT = 1024;     // threads of a partial-sum workgroup
+__global__ __launch_bounds__(GN_PT) void groupnorm_partial_kernel(const unsigned short* __restrict__ x, int V, int C, int vpb,
+                                                                  float* __restrict__ part) {
+    __shared__ float red[GN_PT][17];                 // (sum[8], sumsq[8]) per thread, padded against bank conflicts
     const int nb = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
-    const int oct_per_vox = C >> 3;                  // 16-byte pieces per voxel
+    const int oct_per_vox = C >> 3;                  // 16-byte pieces per voxel (divides 256)
     const int tid = threadIdx.x;
     const int oct = tid % oct_per_vox;               // fixed channel octet of this thread
-    const int vlane = tid / oct_per_vox, vstep = 256 / oct_per_vox;
+    const int vlane = tid / oct_per_vox, vstep = GN_PT / oct_per_vox;
     const int v0 = blk * vpb, v1 = min(V, v0 + vpb);
     float s[8], q[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
     const unsigned short* base = x + ((size_t)nb * V) * C + oct * 8;
-    for (int v = v0 + vlane; v < v1; v += vstep) {
+    int v = v0 + vlane;
+    for (; v + 3 * vstep < v1; v += 4 * vstep) {
+        u16x8 raw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) raw[u] = *(const u16x8*)(base + (size_t)(v + u * vstep) * C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float f = bf16_bits_to_f32(raw[u][e]); s[e] += f; q[e] += f * f; }
+    }
+    for (; v < v1; v += vstep) {
         const u16x8 raw = *(const u16x8*)(base + (size_t)v * C);
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const float f = bf16_bits_to_f32(raw[e]); s[e] += f; q[e] += f * f; }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { red[0][tid][e] = s[e]; red[1][tid][e] = q[e]; }
+    for (int e = 0; e < 8; ++e) { red[tid][e] = s[e]; red[tid][8 + e] = q[e]; }
     __syncthreads();
-    if (tid < oct_per_vox) {                         // fixed-order reduction: deterministic
-        float ts[8], tq[8];
+    // fixed-shape tree over the threads that share a channel octet (tid, tid + stride, ...): deterministic
+    for (int stride = GN_PT / 2; stride >= oct_per_vox; stride >>= 1) {
+        if (tid < stride) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { ts[e] = 0.f; tq[e] = 0.f; }
-        for (int j = tid; j < 256; j += oct_per_vox)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { ts[e] += red[0][j][e]; tq[e] += red[1][j][e]; }
+            for (int e = 0; e < 16; ++e) red[tid][e] += red[tid + stride][e];
+        }
+        __syncthreads();
+    }
+    if (tid < oct_per_vox) {
         float* dst = part + (((size_t)nb * nblk + blk) * 2) * C + tid * 8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { dst[e] = ts[e]; dst[C + e] = tq[e]; }
+        for (int e = 0; e < 8; ++e) { dst[e] = red[tid][e]; dst[C + e] = red[tid][8 + e]; }
     }
 }
 
-// one workgroup per batch item: thread (g, slice) merges blocks slice, slice+S, ... of group g; slices merged in order.
+// One workgroup per batch item: thread (g, slice) adds the (sum, sum of squares) of group g over blocks slice, slice+S, ... in
+// double; slices are added in order; mean and variance from the totals (the partials are fp32 sums, so a double E[x^2]-E[x]^2 is
+// as exact as any merge order of them).
 __global__ __launch_bounds__(256) void groupnorm_finalize_kernel(const float* __restrict__ part, int nblk, int C, int G, int V,
                                                                  int vpb, float eps, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, float* __restrict__ stats,
                                                                  float* __restrict__ affine) {
-    __shared__ double sh_n[256], sh_mean[256], sh_m2[256];
+    __shared__ double sh_s[256], sh_q[256];
     __shared__ float sh_mu[64], sh_rstd[64];
     const int nb = blockIdx.x, tid = threadIdx.x;
     const int S = 256 / G;                       // slices per group (G <= 64)
     const int g = tid / S, sl = tid - g * S;
     const int cpg = C / G;
-    double n_tot = 0.0, mean = 0.0, m2 = 0.0;
+    double ssum = 0.0, qsum = 0.0;
     if (g < G) {
         for (int b = sl; b < nblk; b += S) {
-            const int cnt_v = min(vpb, V - b * vpb);
             const float* ps = part + (((size_t)nb * nblk + b) * 2) * C + g * cpg;
             double s = 0.0, q = 0.0;
             for (int c = 0; c < cpg; ++c) { s += (double)ps[c]; q += (double)ps[C + c]; }
-            const double n_b = (double)cnt_v * cpg;
-            const double mean_b = s / n_b;
-            const double m2_b = fmax(q - s * mean_b, 0.0);
-            const double delta = mean_b - mean;
-            const double n_new = n_tot + n_b;
-            mean += delta * n_b / n_new;
-            m2 += m2_b + delta * delta * n_tot * n_b / n_new;
-            n_tot = n_new;
+            ssum += s; qsum += q;
         }
     }
-    sh_n[tid] = n_tot; sh_mean[tid] = mean; sh_m2[tid] = m2;
+    sh_s[tid] = ssum; sh_q[tid] = qsum;
     __syncthreads();
     if (g < G && sl == 0) {
-        double N = 0.0, mu = 0.0, M2 = 0.0;
-        for (int k = 0; k < S; ++k) {
-            const double n_b = sh_n[tid + k];
-            if (n_b == 0.0) continue;
-            const double delta = sh_mean[tid + k] - mu;
-            const double n_new = N + n_b;
-            mu += delta * n_b / n_new;
-            M2 += sh_m2[tid + k] + delta * delta * N * n_b / n_new;
-            N = n_new;
-        }
-        const float rstd = (float)(1.0 / sqrt(M2 / N + (double)eps));
+        double st = 0.0, qt = 0.0;
+        for (int k = 0; k < S; ++k) { st += sh_s[tid + k]; qt += sh_q[tid + k]; }
+        const double N = (double)V * cpg;
+        const double mu = st / N;
+        const double var = fmax(qt / N - mu * mu, 0.0);
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
         sh_mu[g] = (float)mu; sh_rstd[g] = rstd;
         stats[((size_t)nb * G + g) * 2 + 0] = (float)mu;
         stats[((size_t)nb * G + g) * 2 + 1] = rstd;
@@ -101,6 +105,7 @@ __global__ __launch_bounds__(256) void groupnorm_finalize_kernel(const float* __
         affine[((size_t)nb * 2 + 0) * C + c] = sc;
         affine[((size_t)nb * 2 + 1) * C + c] = beta[c] - sh_mu[gg] * sc;
     }
+    (void)vpb;
 }
 
 // cond[nb, zv, 0, c] = by[c] + sum_j wy[c,j] zq[nb,zv,j];   cond[nb, zv, 1, c] = bb[c] + sum_j wb[c,j] zq[nb,zv,j]
@@ -145,44 +150,59 @@ struct GnApplyArgs {
     int silu;
     const float* cond; int zT, zH, zW;                    // [NB, zT, zH, zW, 2, C] or null
     int tmap[16];                                         // source latent frame of output frame t
-    int rh, log2_rw;                                      // H / zH, log2(W / zW)
+    int rh, log2_cw;                                      // H / zH, log2((W / zW) / RW): runs per latent voxel
 };
 
-// one workgroup per (t, h) row of one batch item; items of a row = W * C/8 sixteen-byte pieces
+// One workgroup per (t, h) row of one batch item.  A thread owns one channel octet (256 % (C/8) == 0, so the octet of item
+// tid + 256k does not depend on k: its affine pair lives in registers) and walks runs of RW consecutive voxels that share one
+// latent voxel: the SpatialNorm3D pair (4 x 16 B of fp32) is fetched once per run instead of once per voxel, and the RW
+// 16-byte loads of a run are all in flight before the first is used.  RW = min(8, W / zW) with conditioning, else the largest
+// of 8, 4, 2, 1 that divides W.
+template <int RW>
 __global__ __launch_bounds__(256) void groupnorm_apply_kernel(GnApplyArgs p) {
     const int nb = blockIdx.y;
     const int t = blockIdx.x / p.H, h = blockIdx.x - t * p.H;
-    const int opv_mask = (1 << p.log2_opv) - 1;
-    const int items = p.W << p.log2_opv;
+    const int opv = 1 << p.log2_opv;
+    const int units = (p.W / RW) << p.log2_opv;
     const unsigned short* xrow = p.x + ((((size_t)nb * p.T + t) * p.H + h) * p.W) * p.C;
     unsigned short* yrow = p.y + ((((size_t)nb * p.oT + t + p.pt) * p.oH + h + p.ph) * p.oW + p.pw) * p.C;
-    const float* aff = p.affine + (size_t)nb * 2 * p.C;
+    const int c0 = (threadIdx.x & (opv - 1)) << 3;
+    const float* aff = p.affine + (size_t)nb * 2 * p.C + c0;
+    const f32x4 s0 = *(const f32x4*)(aff), s1 = *(const f32x4*)(aff + 4);
+    const f32x4 h0 = *(const f32x4*)(aff + p.C), h1 = *(const f32x4*)(aff + p.C + 4);
     const float* crow = nullptr;
-    if (p.cond != nullptr) crow = p.cond + ((((size_t)nb * p.zT + p.tmap[t]) * p.zH + h / p.rh) * p.zW) * 2 * p.C;
-    for (int it = threadIdx.x; it < items; it += 256) {
-        const int w = it >> p.log2_opv, c0 = (it & opv_mask) << 3;
-        const u16x8 raw = *(const u16x8*)(xrow + (size_t)w * p.C + c0);
-        const f32x4 s0 = *(const f32x4*)(aff + c0), s1 = *(const f32x4*)(aff + c0 + 4);
-        const f32x4 h0 = *(const f32x4*)(aff + p.C + c0), h1 = *(const f32x4*)(aff + p.C + c0 + 4);
-        float o[8];
+    if (p.cond != nullptr) crow = p.cond + ((((size_t)nb * p.zT + p.tmap[t]) * p.zH + h / p.rh) * p.zW) * 2 * p.C + c0;
+    for (int u = threadIdx.x; u < units; u += 256) {
+        const int wb = u >> p.log2_opv;
+        const size_t off = (size_t)(wb * RW) * p.C + c0;
+        u16x8 raw[RW];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            o[e] = bf16_bits_to_f32(raw[e]) * s0[e] + h0[e];
-            o[e + 4] = bf16_bits_to_f32(raw[e + 4]) * s1[e] + h1[e];
-        }
+        for (int k = 0; k < RW; ++k) raw[k] = *(const u16x8*)(xrow + off + (size_t)k * p.C);
+        f32x4 y0, y1, b0, b1;
         if (crow != nullptr) {
-            const float* cv = crow + (size_t)(w >> p.log2_rw) * 2 * p.C + c0;
-            const f32x4 y0 = *(const f32x4*)(cv), y1 = *(const f32x4*)(cv + 4);
-            const f32x4 b0 = *(const f32x4*)(cv + p.C), b1 = *(const f32x4*)(cv + p.C + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { o[e] = o[e] * y0[e] + b0[e]; o[e + 4] = o[e + 4] * y1[e] + b1[e]; }
+            const float* cv = crow + (size_t)(wb >> p.log2_cw) * 2 * p.C;
+            y0 = *(const f32x4*)(cv); y1 = *(const f32x4*)(cv + 4);
+            b0 = *(const f32x4*)(cv + p.C); b1 = *(const f32x4*)(cv + p.C + 4);
         }
-        if (p.silu) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = silu(o[e]);
+        for (int k = 0; k < RW; ++k) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = bf16_bits_to_f32(raw[k][e]) * s0[e] + h0[e];
+                o[e + 4] = bf16_bits_to_f32(raw[k][e + 4]) * s1[e] + h1[e];
+            }
+            if (crow != nullptr) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o[e] = o[e] * y0[e] + b0[e]; o[e + 4] = o[e + 4] * y1[e] + b1[e]; }
+            }
+            if (p.silu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = silu(o[e]);
+            }
+            *(uint4*)(yrow + off + (size_t)k * p.C) =
+                make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
         }
-        *(uint4*)(yrow + (size_t)w * p.C + c0) =
-            make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
     }
 }
 
@@ -205,7 +225,7 @@ extern "C" int aether_groupnorm_stats(const void* x, int NB, int V, int C, int G
     if (nblk <= 0 || NB <= 0 || V <= 0) return aether_set_error(AETHER_ERR_ARG, "groupnorm_stats: bad sizes");
     const int vpb = (V + nblk - 1) / nblk;
     const int nblk_eff = (V + vpb - 1) / vpb;
-    hipLaunchKernelGGL(groupnorm_partial_kernel, dim3(nblk_eff, NB), dim3(256), 0, AE_STREAM, (const unsigned short*)x, V, C, vpb, partial_ws);
+    hipLaunchKernelGGL(groupnorm_partial_kernel, dim3(nblk_eff, NB), dim3(GN_PT), 0, AE_STREAM, (const unsigned short*)x, V, C, vpb, partial_ws);
     int rc = aether_check_launch("groupnorm_partial");
     if (rc) return rc;
     hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(NB), dim3(256), 0, AE_STREAM, partial_ws, nblk_eff, C, G, V, vpb, eps, gamma, beta,
@@ -228,7 +248,8 @@ extern "C" int aether_groupnorm_apply(const void* x, int NB, int T, int H, int W
                                       const int* tmap_host, void* stream) {
     if (!x || !y || !affine) return aether_set_error(AETHER_ERR_ARG, "groupnorm_apply: null pointer");
     const int l2 = ilog2_exact(C / 8);
-    if (C % 8 != 0 || l2 < 0) return aether_set_error(AETHER_ERR_SHAPE, "groupnorm_apply: C/8 must be a power of two");
+    if (C % 8 != 0 || l2 < 0 || l2 > 8) return aether_set_error(AETHER_ERR_SHAPE, "groupnorm_apply: C/8 must be a power of two <= 256");
+    int rw = 1;
     if (T + pt > oT || H + ph > oH || W + pw > oW) return aether_set_error(AETHER_ERR_SHAPE, "groupnorm_apply: output volume too small");
     GnApplyArgs p = {};
     p.x = (const unsigned short*)x; p.T = T; p.H = H; p.W = W; p.C = C; p.log2_opv = l2;
@@ -238,12 +259,22 @@ extern "C" int aether_groupnorm_apply(const void* x, int NB, int T, int H, int W
         if (!tmap_host || T > 16 || zT <= 0 || zH <= 0 || zW <= 0 || H % zH || W % zW) return aether_set_error(AETHER_ERR_SHAPE, "groupnorm_apply: unsupported latent volume");
         const int lrw = ilog2_exact(W / zW);
         if (lrw < 0) return aether_set_error(AETHER_ERR_SHAPE, "groupnorm_apply: W / zW must be a power of two");
-        p.cond = cond; p.zT = zT; p.zH = zH; p.zW = zW; p.rh = H / zH; p.log2_rw = lrw;
+        p.cond = cond; p.zT = zT; p.zH = zH; p.zW = zW; p.rh = H / zH;
+        rw = lrw > 3 ? 8 : (1 << lrw);
+        p.log2_cw = lrw > 3 ? lrw - 3 : 0;
         for (int t = 0; t < T; ++t) {
             if (tmap_host[t] < 0 || tmap_host[t] >= zT) return aether_set_error(AETHER_ERR_ARG, "groupnorm_apply: time map out of range");
             p.tmap[t] = tmap_host[t];
         }
+    } else {
+        rw = (W % 8 == 0) ? 8 : (W % 4 == 0) ? 4 : (W % 2 == 0) ? 2 : 1;
     }
-    hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(T * H, NB), dim3(256), 0, AE_STREAM, p);
+    const dim3 grid(T * H, NB), block(256);
+    switch (rw) {
+        case 8: hipLaunchKernelGGL(groupnorm_apply_kernel<8>, grid, block, 0, AE_STREAM, p); break;
+        case 4: hipLaunchKernelGGL(groupnorm_apply_kernel<4>, grid, block, 0, AE_STREAM, p); break;
+        case 2: hipLaunchKernelGGL(groupnorm_apply_kernel<2>, grid, block, 0, AE_STREAM, p); break;
+        default: hipLaunchKernelGGL(groupnorm_apply_kernel<1>, grid, block, 0, AE_STREAM, p); break;
+    }
     return aether_check_launch("groupnorm_apply");
 }

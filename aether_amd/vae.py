@@ -375,17 +375,15 @@ class AetherVAE:
         _lib.check(rc, "aether_resample_pad")
         return vol
 
-    @staticmethod
-    def _causal_front(vol: torch.Tensor, cache: Dict, key: str):
+    def _causal_front(self, vol: torch.Tensor, cache: Dict, key: str):
         """Fill the two causal front frames of a padded conv input from the cache of the previous chunk (or by
-        replicating the first frame), then remember this chunk's last two input frames (CogVideoXCausalConv3d)."""
+        replicating the first frame), then remember this chunk's last two input frames (CogVideoXCausalConv3d): one launch."""
         prev = cache.get(key)
-        if prev is None:
-            vol[:, 0].copy_(vol[:, 2])
-            vol[:, 1].copy_(vol[:, 2])
-        else:
-            vol[:, :2].copy_(prev)
-        cache[key] = vol[:, -2:].clone()
+        NB, Tp = vol.shape[0], vol.shape[1]
+        nxt = torch.empty((NB, 2) + tuple(vol.shape[2:]), dtype=vol.dtype, device=vol.device)
+        _lib.check(self._lib.aether_causal_front(vol.data_ptr(), NB, Tp, vol[0, 0].numel(), _lib.ptr(prev), nxt.data_ptr(), self._stream()),
+                   "aether_causal_front")
+        cache[key] = nxt
 
     def _causal_conv(self, x, norm, conv, cache, key, silu=True, zq=None, residual=None, eps=None):
         NB, T, H, W, _ = x.shape

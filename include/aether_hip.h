@@ -167,6 +167,12 @@ int aether_groupnorm_apply(const void* x, int NB, int T, int H, int W, int C, co
                            int oT, int oH, int oW, int pt, int ph, int pw, const float* cond, int zT, int zH, int zW,
                            const int* tmap_host, void* stream);
 
+/* Causal front of a convolution input vol [NB, Tp, Hp, Wp, C] whose frames 2..Tp-1 are already written (CogVideoXCausalConv3d:
+ * two frames of temporal context in front, from the previous chunk's `conv_cache` or by repeating the first frame):
+ * frames 0,1 := prev [NB, 2, Hp, Wp, C], or copies of frame 2 when prev is NULL;  next [NB, 2, Hp, Wp, C] := the last two
+ * frames of vol after that fill (the cache for the following chunk).  frame_elems = Hp*Wp*C.  One launch. */
+int aether_causal_front(void* vol, int NB, int Tp, long frame_elems, const void* prev, void* next, void* stream);
+
 /* Resample x [NB,T,H,W,C] into a zero-bordered volume y [NB,oT,oH,oW,C] at interior offset (pt,ph,pw).
  * mode 0 copy; 1 temporal avg-pool k2 s2 (first frame kept when T is odd; CogVideoXDownsample3D);
  * 2 nearest x2 in space; 3 nearest x2 in space and time with the first-frame rule of CogVideoXUpsample3D. */

@@ -259,3 +259,76 @@ def test_vae_full_width_decode_chunk(cuda, hip_lib):
     print(f"full-width encode: native {e_n:.3e}  bf16-oracle {e_16:.3e}")
     assert e_n < 1.5 * e_16 + 3e-3
     _ = C
+
+
+@pytest.mark.parametrize("Cc,W,zW,nblk", [(128, 16, 2, 1), (64, 6, 3, 3), (256, 5, 5, 2), (128, 32, 2, 7), (512, 40, 0, 2), (64, 7, 0, 5)])
+def test_groupnorm_run_lengths_and_long_blocks(cuda, hip_lib, Cc, W, zW, nblk):
+    """Every run length of the apply kernel (W / zW = 8, 2, 1, 16; no conditioning with W % 8 == 0 and odd W) and partial-sum
+    workgroups long enough to take the four-loads-per-iteration path (few blocks over many voxels)."""
+    import ctypes as C
+    from aether_amd import _lib
+    from aether_amd.vae import _nearest_time_map
+    g = torch.Generator().manual_seed(Cc + W)
+    NB, T, H, G = 2, 4, 36, 32
+    x = (torch.randn(NB, T, H, W, Cc, generator=g) * 1.5 - 0.4).to(torch.bfloat16)
+    xs = x.to(cuda)
+    gamma = (1 + 0.1 * torch.randn(Cc, generator=g)).to(cuda)
+    beta = (0.1 * torch.randn(Cc, generator=g)).to(cuda)
+    V = T * H * W
+    part = torch.empty(NB * nblk * 2 * Cc, dtype=torch.float32, device=cuda)
+    stats = torch.empty(NB, G, 2, dtype=torch.float32, device=cuda)
+    affine = torch.empty(NB, 2, Cc, dtype=torch.float32, device=cuda)
+    st = _lib.current_stream()
+    _lib.check(hip_lib.aether_groupnorm_stats(xs.data_ptr(), NB, V, Cc, G, 1e-6, gamma.data_ptr(), beta.data_ptr(), part.data_ptr(), nblk,
+                                              stats.data_ptr(), affine.data_ptr(), st), "stats")
+    xg = x.double().reshape(NB, V, G, Cc // G)
+    mu = xg.mean(dim=(1, 3))
+    var = xg.var(dim=(1, 3), unbiased=False)
+    torch.cuda.synchronize()
+    assert torch.allclose(stats[..., 0].cpu().double(), mu, atol=2e-5, rtol=1e-5)
+    assert torch.allclose(stats[..., 1].cpu().double(), 1 / torch.sqrt(var + 1e-6), rtol=2e-5)
+    # apply (+ optional SpatialNorm3D pair gathered at the nearest latent voxel) against the same formula in fp64
+    vol = torch.zeros(NB, T + 2, H + 2, W + 2, Cc, dtype=torch.bfloat16, device=cuda)
+    aff = affine.cpu()
+    ref = (x.float() * aff[:, 0].view(NB, 1, 1, 1, Cc) + aff[:, 1].view(NB, 1, 1, 1, Cc)).double()
+    if zW:
+        zT, zH = 2, H // 4
+        cond = torch.randn(NB, zT, zH, zW, 2, Cc, generator=g)
+        tmap = _nearest_time_map(T, zT)
+        idx_t = torch.tensor(tmap)
+        idx_h = torch.arange(H) // (H // zH)
+        idx_w = torch.arange(W) // (W // zW)
+        cg = cond[:, idx_t][:, :, idx_h][:, :, :, idx_w].double()              # [NB, T, H, W, 2, C]
+        ref = ref * cg[..., 0, :] + cg[..., 1, :]
+        condd = cond.to(cuda)
+        rc = hip_lib.aether_groupnorm_apply(xs.data_ptr(), NB, T, H, W, Cc, affine.data_ptr(), 1, vol.data_ptr(), T + 2, H + 2, W + 2, 2, 1, 1,
+                                            condd.data_ptr(), zT, zH, zW, (C.c_int * T)(*tmap), st)
+    else:
+        rc = hip_lib.aether_groupnorm_apply(xs.data_ptr(), NB, T, H, W, Cc, affine.data_ptr(), 1, vol.data_ptr(), T + 2, H + 2, W + 2, 2, 1, 1,
+                                            None, 0, 0, 0, None, st)
+    _lib.check(rc, "apply")
+    ref = ref * torch.sigmoid(ref)
+    torch.cuda.synchronize()
+    assert _rel(vol[:, 2:, 1:-1, 1:-1].cpu(), ref.float()) < 4e-3
+    assert float(vol[:, :2].abs().max()) == 0 and float(vol[:, :, 0].abs().max()) == 0 and float(vol[:, :, :, -1].abs().max()) == 0
+
+
+@pytest.mark.parametrize("T", [1, 2, 5])
+def test_causal_front_single_launch(cuda, hip_lib, T):
+    """Front frames from the previous chunk's cache (or copies of the first frame) and the cache for the next chunk, against
+    the three tensor copies they replace; T = 1 makes the new cache overlap the front frames."""
+    vae = _vae(cuda)
+    g = torch.Generator().manual_seed(T)
+    NB, H, W, Cc = 2, 5, 7, 64
+    for with_prev in (False, True):
+        vol = torch.randn(NB, T + 2, H + 2, W + 2, Cc, generator=g).to(torch.bfloat16).to(cuda)
+        prev = torch.randn(NB, 2, H + 2, W + 2, Cc, generator=g).to(torch.bfloat16).to(cuda) if with_prev else None
+        ref = vol.clone()
+        if prev is None:
+            ref[:, 0].copy_(ref[:, 2]); ref[:, 1].copy_(ref[:, 2])
+        else:
+            ref[:, :2].copy_(prev)
+        cache = {} if prev is None else {"k": prev}
+        vae._causal_front(vol, cache, "k")
+        torch.cuda.synchronize()
+        assert torch.equal(vol, ref) and torch.equal(cache["k"], ref[:, -2:])

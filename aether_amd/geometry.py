@@ -8,6 +8,7 @@ reference); it is pinned against the reference's own functions by tests/golden/b
 """
 from __future__ import annotations
 
+import math
 from typing import Optional, Tuple
 
 import numpy as np
@@ -56,6 +57,43 @@ def get_rays(pose: np.ndarray, h: int, w: int, focal):
         rays_d[t] += R[None, None, :, 2]
     rays_o = np.broadcast_to(p32[:, None, None, :3, 3], rays_d.shape).copy()
     return rays_o, rays_d, K
+
+
+def signed_log1p(x: np.ndarray) -> np.ndarray:
+    return np.sign(x) * np.log1p(np.abs(x))
+
+
+def camera_pose_to_raymap(camera_pose: np.ndarray, intrinsic: np.ndarray, ray_o_scale_factor: float = 10.0, dmax: float = 1.0,
+                          H: int = 480, W: int = 720, vae_downsample: int = 8, align_corners: bool = False) -> np.ndarray:
+    """U:867-961 (the README recipe for `--raymap_action`): camera-to-world poses [N,4,4] + intrinsics [N,3,3] -> raymap
+    [N,6,H/8,W/8] float32: channels 0-2 = R·((u-cu)/fu, (v-cv)/fv, 1) of the full-resolution pixel grid, bilinearly resized
+    by 1/vae_downsample; channels 3-5 = signed_log1p(t · dmax · ray_o_scale_factor), constant over the frame.
+    The reference resizes a full-resolution ray image; the ray direction is affine in (u, v) and bilinear resizing reproduces
+    affine functions, so the same values come from evaluating it at the resize's source coordinates (i + 0.5)·s - 0.5
+    (align_corners=False) or i·(n_in - 1)/(n_out - 1) (True).  Unlike the reference (float32 input only) this never writes into
+    the caller's `camera_pose`."""
+    pose = np.asarray(camera_pose, np.float32)
+    Kf = np.asarray(intrinsic, np.float32)
+    N = pose.shape[0]
+    h, w = (H, W) if vae_downsample == 1 else (int(math.floor(H / vae_downsample)), int(math.floor(W / vae_downsample)))
+
+    def source(n_out, n_in):
+        i = np.arange(n_out, dtype=np.float32)
+        if vae_downsample == 1:
+            return i
+        if align_corners:
+            return i * np.float32((n_in - 1) / (n_out - 1)) if n_out > 1 else np.zeros(1, np.float32)
+        return (i + np.float32(0.5)) * np.float32(vae_downsample) - np.float32(0.5)
+
+    u, v = source(w, W), source(h, H)
+    x = (u[None, :] - Kf[:, 0, 2, None]) / Kf[:, 0, 0, None]                       # [N, w]
+    y = (v[None, :] - Kf[:, 1, 2, None]) / Kf[:, 1, 1, None]                       # [N, h]
+    R = pose[:, :3, :3]
+    d = (R[:, :, 0, None, None] * x[:, None, None, :] + R[:, :, 1, None, None] * y[:, None, :, None]
+         + R[:, :, 2, None, None])                                                  # [N, 3, h, w]
+    t = signed_log1p(pose[:, :3, 3] * np.float32(dmax) * np.float32(ray_o_scale_factor)).astype(np.float32)
+    o = np.broadcast_to(t[:, :, None, None], (N, 3, h, w))
+    return np.concatenate([d.astype(np.float32), o], axis=1)
 
 
 def raymap_to_poses(raymap: np.ndarray, camera_pose: Optional[np.ndarray] = None, ray_o_scale_inv: float = 1.0,

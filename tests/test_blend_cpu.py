@@ -84,3 +84,24 @@ def test_kalman_branch_runs_and_is_smooth():
     assert s.shape == p.shape and np.isfinite(s).all()
     assert np.allclose(np.einsum("nij,nkj->nik", s[:, :3, :3], s[:, :3, :3]), np.eye(3), atol=1e-9)
     assert np.abs(s[:, :3, 3] - p[:, :3, 3]).max() < 0.5 * np.abs(np.diff(p[:, :3, 3], axis=0)).max() * len(p)
+
+
+def test_camera_pose_to_raymap_matches_reference_and_round_trips():
+    """The README recipe for `--raymap_action` (U:919-961): encoder against the reference's output, decoder against its
+    raymap_to_poses on that raymap, and the caller's poses left untouched."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "raymap.npz"))
+    n = len(z["poses"])
+    poses32 = z["poses"].astype(np.float32)
+    keep = poses32.copy()
+    ray = G.camera_pose_to_raymap(poses32, np.tile(z["K"], (n, 1, 1)))
+    assert ray.shape == (n, 6, 60, 90) and ray.dtype == np.float32 and np.array_equal(poses32, keep)
+    np.testing.assert_allclose(ray, z["raymap"], atol=1e-6, rtol=0)
+    rec, fov_x, fov_y = G.raymap_to_poses(ray.copy(), ray_o_scale_inv=0.1)
+    np.testing.assert_allclose(rec, z["rec_poses"], atol=2e-6)
+    np.testing.assert_allclose(fov_x, z["fov_x"], rtol=1e-5)
+    np.testing.assert_allclose(fov_y, z["fov_y"], rtol=1e-5)
+    np.testing.assert_allclose(rec[:, :3, 3], z["poses"][:, :3, 3], atol=2e-3)       # the trajectory survives encode -> decode
+    # full resolution / align_corners variants stay consistent with the 1/8 grid (affine in the pixel coordinates)
+    full = G.camera_pose_to_raymap(poses32, np.tile(z["K"], (n, 1, 1)), vae_downsample=1)
+    assert full.shape == (n, 6, 480, 720)
+    np.testing.assert_allclose(0.5 * (full[:, :3, 3::8, 3::8] + full[:, :3, 4::8, 4::8]), ray[:, :3], atol=1e-6)

@@ -48,6 +48,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "raymap.npz"), poses=poses, K=K, raymap=raymap.astype(np.float32),
                         rec_poses=rec_poses, fov_x=np.asarray(fov_x), fov_y=np.asarray(fov_y))
     make_blend_golden(U)
+    make_eval_golden(U)
     print("wrote", os.listdir(OUT))
 
 
@@ -124,6 +125,85 @@ def make_blend_golden(U):
     # poses / scalars stay float64; images and point maps are stored as float32 (tests compare at 1e-5)
     small = {k: (v.astype(np.float32) if isinstance(v, np.ndarray) and v.dtype == np.float64 and v.size > 1000 else v) for k, v in out.items()}
     np.savez_compressed(os.path.join(OUT, "blend.npz"), **small)
+
+
+def _reference_function(path, name, ns):
+    """Executes ONE top-level function of a reference script (whose module cannot be imported here: imageio / accelerate / cv2
+    imports, CUDA generators) in the namespace `ns`; nothing of it is stored in this repository but its outputs."""
+    import ast
+    node = next(n for n in ast.parse(open(os.path.join(REF, path)).read()).body if isinstance(n, ast.FunctionDef) and n.name == name)
+    exec(compile(ast.Module(body=[node], type_ignores=[]), "reference_" + name, "exec"), ns)
+    return ns[name]
+
+
+def eval_pattern(t, h, w):
+    """Exactly reproducible clip (integer arithmetic only) shared by this generator and tests/test_eval_windows_cpu.py."""
+    tt, yy, xx = np.meshgrid(np.arange(t), np.arange(h), np.arange(w), indexing="ij")
+    base = ((xx * 7 + yy * 13 + tt * 29) % 101).astype(np.float32) / np.float32(101)
+    third = ((xx + 2 * yy + 3 * tt) % 50).astype(np.float32) / np.float32(50)
+    return np.stack([base, base * np.float32(0.5) + np.float32(0.25), third], -1)[None]
+
+
+class EvalFakePipeline:
+    """Stand-in for the pipeline: a deterministic function of the crop and of the call index (so every unit has its own
+    disparity scale and the merge has something to align)."""
+    def __init__(self):
+        self.calls = 0
+
+    def __call__(self, video, num_inference_steps, num_frames, generator, return_dict, fps):
+        k, self.calls = self.calls, self.calls + 1
+        v = np.ascontiguousarray(video, dtype=np.float32)
+        assert v.shape[0] == num_frames and v.shape[1:3] == (480, 720) and not return_dict and fps == 12
+        disp = ((np.float32(0.15) + np.float32(0.8) * v.mean(-1, dtype=np.float32)) * np.float32(1.0 + 0.07 * ((k * 5) % 7))).astype(np.float32)
+        return v[None], disp[None], np.zeros((1, v.shape[0], 6, 60, 90), np.float32)
+
+
+def make_eval_golden(U):
+    """Evaluation-harness windows: the reference's process_with_sliding_window (video depth) on two
+    procedurally generated clips, and its blend_window_outputs (relative pose, with the Kalman smoother — which needs the
+    absent filterpy — replaced by the identity) on three small overlapping windows."""
+    import math
+    import types as _t
+
+    import torch
+    torch_shim = _t.SimpleNamespace(Generator=lambda device=None: torch.Generator())      # the reference asks for device="cuda"
+    fn = _reference_function("evaluation/video_depth/launch_aether.py", "process_with_sliding_window",
+                             dict(np=np, math=math, torch=torch_shim, compute_scale=U.compute_scale))
+    out = {}
+    for tag, (t, h, w, total) in {"wide": (25, 480, 900, 17), "tall": (17, 600, 720, 17), "plain": (33, 480, 720, 30)}.items():
+        rgb, disp = fn(EvalFakePipeline(), eval_pattern(t, h, w), 4, total, 7)
+        out[f"{tag}_dims"] = np.array([t, h, w, total])
+        out[f"{tag}_rgb_shape"], out[f"{tag}_rgb_sum"] = np.array(rgb.shape), np.array(rgb.sum(dtype=np.float64))
+        out[f"{tag}_disp_shape"], out[f"{tag}_disp_sum"] = np.array(disp.shape), np.array(np.asarray(disp, np.float64).sum())
+        out[f"{tag}_disp_sub"] = np.asarray(disp, np.float64)[::3, ::7, ::11]
+
+    blend = _reference_function("evaluation/rel_pose/launch_aether.py", "blend_window_outputs",
+                                dict(np=np, torch=torch, compute_scale=U.compute_scale, align_camera_extrinsics=U.align_camera_extrinsics,
+                                     apply_transformation=U.apply_transformation, interpolate_poses=U.interpolate_poses,
+                                     smooth_trajectory=lambda poses, window_size=5: poses))
+    rng = np.random.default_rng(11)
+    N, F, starts = 19, 9, [0, 5, 10]
+    tt = np.linspace(0, 1, N)
+    world = np.tile(np.eye(4), (N, 1, 1))
+    ang = 0.6 * tt
+    world[:, 0, 0], world[:, 0, 2], world[:, 2, 0], world[:, 2, 2] = np.cos(ang), np.sin(ang), -np.sin(ang), np.cos(ang)
+    world[:, 0, 3], world[:, 1, 3], world[:, 2, 3] = 0.4 * tt, 0.03 * np.sin(5 * tt), 1.1 * tt
+    wins = []
+    for k, s0 in enumerate(starts):
+        rel = np.linalg.inv(world[s0]) @ world[s0:s0 + F]
+        rel[:, :3, 3] *= (1.0, 0.8, 1.25)[k]
+        rel[:, :3, 3] += 1e-3 * rng.standard_normal((F, 3))
+        wins.append({"rgb": rng.random((F, 6, 8, 3)), "disparity": ((0.9, 1.3, 0.7)[k] * (0.2 + 0.6 * rng.random((F, 6, 8)))).astype(np.float32),
+                     "poses": rel[:, :3, :4].copy(), "focals": 500 + 20 * rng.random(F), "range": (s0, s0 + F)})
+    for k, wd in enumerate(wins):
+        for key in ("rgb", "disparity", "poses", "focals"):
+            out[f"pose_in_{k}_{key}"] = wd[key].copy()
+        out[f"pose_in_{k}_range"] = np.array(wd["range"])
+    res = blend([{k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in wd.items()} for wd in wins])
+    for key in ("rgb", "disparity", "poses", "focals"):
+        out[f"pose_out_{key}"] = res[key]
+    out["pose_out_range"] = np.array(res["range"])
+    np.savez_compressed(os.path.join(OUT, "eval_windows.npz"), **out)
 
 
 if __name__ == "__main__":

@@ -11,7 +11,7 @@
 //   aether_im2col_first        explicit im2col for the two thin first convs (3 -> 128, 16 -> 512 channels)
 //   (GroupNorm / SpatialNorm3D kernels live in vae_norm.hip)
 //   aether_time_avgpool_pad / aether_upsample_nearest_pad / aether_pad_copy   resamplers writing padded volumes
-#include "gemm_kernel.hpp"
+#include "conv3_kernel.hpp"
 #include "../../include/aether_hip.h"
 
 namespace aether {
@@ -189,6 +189,26 @@ extern "C" int aether_conv_gemm_bf16(const void* X, int NB, int iT, int iH, int 
     p.a_bytes = (unsigned)((size_t)NB * iT * iH * iW * iC * 2);
     p.w_bytes = (unsigned)((size_t)Cout * K * 2);
     dim3 block(512);
+    // Tap-reuse kernel (conv3_kernel.hpp): 3x3(x3) taps in (dt, dh, channel block, dw) order, unit stride, one-voxel zero border
+    // in H and W.  Output rows enumerate the padded plane, so it pays where the border is a small share of the plane.
+    if ((flags & AETHER_CONV_TAP_REUSE) && stride_hw == 1 && n_taps % 3 == 0 && iW == oW + 2 && iH == oH + 2 && oH >= 3 &&
+        (iT == oT + 2 || iT == oT) && Cout % 128 == 0 && (long)NB * oT * iH * iW < (1l << 31)) {
+        p.M = NB * oT * iH * iW;
+        p.ksplit = 1;
+#define LAUNCH_C3(WM_, WN_, MT_, NT_, BM_, BN_)                                                                                     \
+        do {                                                                                                                        \
+            p.tiles_m = (p.M + BM_ - 1) / BM_; p.tiles_n = (Cout + BN_ - 1) / BN_; p.ntile_launch = p.tiles_m * p.tiles_n;            \
+            dim3 grid(p.ntile_launch);                                                                                              \
+            if (R) { if (wide) hipLaunchKernelGGL((conv3_gemm_kernel<WM_, WN_, MT_, NT_, EPI_BIAS_GATE_RES, true>), grid, block, 0, AE_STREAM, p);  \
+                     else hipLaunchKernelGGL((conv3_gemm_kernel<WM_, WN_, MT_, NT_, EPI_BIAS_GATE_RES, false>), grid, block, 0, AE_STREAM, p); }   \
+            else { if (wide) hipLaunchKernelGGL((conv3_gemm_kernel<WM_, WN_, MT_, NT_, EPI_BIAS, true>), grid, block, 0, AE_STREAM, p);            \
+                   else hipLaunchKernelGGL((conv3_gemm_kernel<WM_, WN_, MT_, NT_, EPI_BIAS, false>), grid, block, 0, AE_STREAM, p); }               \
+        } while (0)
+        if (Cout % 256 == 0) LAUNCH_C3(2, 4, 4, 2, 256, 256);
+        else LAUNCH_C3(4, 2, 3, 2, 384, 128);
+#undef LAUNCH_C3
+        return aether_check_launch("conv3_gemm_bf16");
+    }
     // split-K when the output tiles cannot fill the chip (one 128-KiB-LDS workgroup per CU, 256 CUs): the deep layers have
     // K = 27*512 = 216 K tiles walked serially by a handful of workgroups otherwise.  Slices >= 4 K tiles, total <= 256 WGs.
     auto pick_ksplit = [&](int tiles) {

@@ -144,6 +144,7 @@ class AetherVAE:
         self._taps: Dict[tuple, torch.Tensor] = {}
         self._splitk_ws: Optional[torch.Tensor] = None       # fp32 scratch for split-K partial tiles (allocated on first use)
         self.splitk_ws_bytes = 96 << 20
+        self.tap_reuse_max_waste = 1.06                       # padded-plane / output-plane ratio up to which the tap-reuse conv runs (0: never)
         self._loaded = False
 
     # ------------------------------------------------------------------------------------------------
@@ -319,11 +320,17 @@ class AetherVAE:
         out = torch.empty(NB, oT, oH, oW, conv.cout_pad, dtype=torch.bfloat16, device=self.device)
         if self._splitk_ws is None and self.splitk_ws_bytes:
             self._splitk_ws = torch.empty(self.splitk_ws_bytes // 4, dtype=torch.float32, device=self.device)
+        flags = self._flags
+        # tap-reuse kernel: needs the (dt, dh, channel block, dw) K order and pays where the one-voxel border is a small share
+        # of the plane it enumerates (240x360: 1.4 %, 120x180: 2.8 %, 60x90: 5.6 %; at 30x45 the split-K plain kernel wins)
+        if (conv.blocked and stride == 1 and kh == 3 and kw == 3 and iH == oH + 2 and iW == oW + 2
+                and iH * iW <= self.tap_reuse_max_waste * oH * oW):
+            flags |= _lib.AETHER_CONV_TAP_REUSE
         rc = self._lib.aether_conv_gemm_bf16(vol.data_ptr(), NB, iT, iH, iW, iC, oT, oH, oW, stride, taps.data_ptr(), taps.numel(),
                                              conv.w.data_ptr(), conv.cout_pad, out.data_ptr(), conv.cout_pad, conv.b.data_ptr(),
                                              _lib.ptr(residual), conv.cout_pad if residual is not None else 0,
                                              _lib.ptr(self._splitk_ws), self.splitk_ws_bytes if self._splitk_ws is not None else 0,
-                                             self._flags, self._stream())
+                                             flags, self._stream())
         _lib.check(rc, "aether_conv_gemm_bf16")
         return out
 

@@ -135,7 +135,12 @@ int aether_flash_attn_fwd(const void* Qh, const void* Kh, const void* Vt, void* 
  * R (bf16 [M, Cout], ldr) is added when non-NULL (ResNet skip).
  * splitk_ws (fp32 scratch of splitk_ws_bytes, may be NULL): launches with <= 128 output tiles (the deep low-resolution
  * layers, K = 27*512) split their K loop over up to 256/tiles workgroups per tile; the fp32 partial tiles are summed in
- * slice order (deterministic) by a finalize kernel that also applies bias / R and rounds to bf16. */
+ * slice order (deterministic) by a finalize kernel that also applies bias / R and rounds to bf16.
+ * flags bit 7 (AETHER_CONV_TAP_REUSE): the caller states that the K order is (dt, dh, 64-channel block, dw) with dw fastest,
+ * i.e. tap_off[3j+1] = tap_off[3j] + iC and tap_off[3j+2] = tap_off[3j] + 2*iC.  For a 3x3(x3) stride-1 convolution with
+ * Cout % 128 == 0 the library may then run the tap-reuse kernel (one staged input tile serves the three dw taps); results
+ * equal the plain kernel's up to fp32 summation order (the K order inside an output is the same: bit-identical). */
+#define AETHER_CONV_TAP_REUSE 128
 int aether_conv_gemm_bf16(const void* X, int NB, int iT, int iH, int iW, int iC, int oT, int oH, int oW, int stride_hw,
                           const int* tap_off, int n_taps, const void* W, int Cout, void* C, int ldc, const float* bias,
                           const void* R, int ldr, float* splitk_ws, size_t splitk_ws_bytes, int flags, void* stream);

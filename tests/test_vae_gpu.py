@@ -332,3 +332,31 @@ def test_causal_front_single_launch(cuda, hip_lib, T):
         vae._causal_front(vol, cache, "k")
         torch.cuda.synchronize()
         assert torch.equal(vol, ref) and torch.equal(cache["k"], ref[:, -2:])
+
+
+@pytest.mark.parametrize("cin,cout,NB,T,H,W,kt,res", [(128, 128, 1, 2, 12, 20, 3, False), (64, 256, 2, 3, 9, 33, 3, True),
+                                                      (256, 128, 1, 1, 30, 45, 3, True), (128, 256, 2, 2, 16, 24, 1, False),
+                                                      (64, 128, 3, 1, 5, 7, 1, True), (512, 512, 1, 2, 40, 61, 3, False)])
+def test_conv_tap_reuse_is_bit_identical(cuda, hip_lib, cin, cout, NB, T, H, W, kt, res):
+    """conv3_kernel.hpp (one staged input tile for the three dw taps, rows enumerated over the padded plane) against the
+    plain gathered kernel: same K order inside every output -> the same bits; tiles that straddle frames, batch items and
+    the dropped border rows, with and without the residual epilogue, causal 3x3x3 and per-frame 3x3."""
+    from aether_amd import _lib
+    from aether_amd.vae import _Conv
+    g = torch.Generator().manual_seed(cin + cout + H)
+    shape = (cout, cin, 3, 3, 3) if kt == 3 else (cout, cin, 3, 3)
+    conv = _Conv(torch.randn(shape, generator=g) * 0.05, torch.randn(cout, generator=g) * 0.1, cuda)
+    assert conv.blocked
+    vae = _vae(cuda)
+    vae.splitk_ws_bytes = 0                      # the small plain launches would otherwise split K (another summation order)
+    vol = torch.zeros(NB, T + (2 if kt == 3 else 0), H + 2, W + 2, cin, dtype=torch.bfloat16, device=cuda)
+    vol[:, :, 1:-1, 1:-1] = torch.randn(NB, vol.shape[1], H, W, cin, generator=g).to(torch.bfloat16).to(cuda)
+    R = torch.randn(NB, T, H, W, cout, generator=g).to(torch.bfloat16).to(cuda) if res else None
+    outs = []
+    for waste, wide in ((0.0, True), (100.0, True), (100.0, False)):
+        vae.tap_reuse_max_waste = waste
+        vae._flags = (_lib.AETHER_GEMM_WIDE_STORE if wide else 0) | _lib.AETHER_GEMM_PINGPONG
+        outs.append(vae._conv(vol, conv, (T, H, W), 1, R))
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[0].float()).all() and float(outs[0].float().abs().max()) > 0.1
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])

@@ -63,49 +63,46 @@ __global__ __launch_bounds__(GN_PT) void groupnorm_partial_kernel(const unsigned
     }
 }
 
-// One workgroup per batch item: thread (g, slice) adds the (sum, sum of squares) of group g over blocks slice, slice+S, ... in
-// double; slices are added in order; mean and variance from the totals (the partials are fp32 sums, so a double E[x^2]-E[x]^2 is
-// as exact as any merge order of them).
+// One workgroup per (group, batch item): thread b adds the group's channels of partial block b, b+256, ... in double, a fixed-
+// shape LDS tree adds the threads (deterministic), thread 0 turns the totals into mean / rstd (the partials are fp32 sums, so
+// a double E[x^2]-E[x]^2 is as exact as any merge order of them) and the group's channels get their folded affine pair.
+// (One workgroup per batch item walked all G x nblk partial rows through a single CU's texture path: 15-28 us; this spreads
+// them over G CUs.)
 __global__ __launch_bounds__(256) void groupnorm_finalize_kernel(const float* __restrict__ part, int nblk, int C, int G, int V,
-                                                                 int vpb, float eps, const float* __restrict__ gamma,
+                                                                 float eps, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, float* __restrict__ stats,
                                                                  float* __restrict__ affine) {
     __shared__ double sh_s[256], sh_q[256];
-    __shared__ float sh_mu[64], sh_rstd[64];
-    const int nb = blockIdx.x, tid = threadIdx.x;
-    const int S = 256 / G;                       // slices per group (G <= 64)
-    const int g = tid / S, sl = tid - g * S;
+    __shared__ float sh_mu, sh_rstd;
+    const int g = blockIdx.x, nb = blockIdx.y, tid = threadIdx.x;
     const int cpg = C / G;
     double ssum = 0.0, qsum = 0.0;
-    if (g < G) {
-        for (int b = sl; b < nblk; b += S) {
-            const float* ps = part + (((size_t)nb * nblk + b) * 2) * C + g * cpg;
-            double s = 0.0, q = 0.0;
-            for (int c = 0; c < cpg; ++c) { s += (double)ps[c]; q += (double)ps[C + c]; }
-            ssum += s; qsum += q;
-        }
+    for (int b = tid; b < nblk; b += 256) {
+        const float* ps = part + (((size_t)nb * nblk + b) * 2) * C + g * cpg;
+        for (int c = 0; c < cpg; ++c) { ssum += (double)ps[c]; qsum += (double)ps[C + c]; }
     }
     sh_s[tid] = ssum; sh_q[tid] = qsum;
     __syncthreads();
-    if (g < G && sl == 0) {
-        double st = 0.0, qt = 0.0;
-        for (int k = 0; k < S; ++k) { st += sh_s[tid + k]; qt += sh_q[tid + k]; }
+    for (int stride = 128; stride > 0; stride >>= 1) {
+        if (tid < stride) { sh_s[tid] += sh_s[tid + stride]; sh_q[tid] += sh_q[tid + stride]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
         const double N = (double)V * cpg;
-        const double mu = st / N;
-        const double var = fmax(qt / N - mu * mu, 0.0);
+        const double mu = sh_s[0] / N;
+        const double var = fmax(sh_q[0] / N - mu * mu, 0.0);
         const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-        sh_mu[g] = (float)mu; sh_rstd[g] = rstd;
+        sh_mu = (float)mu; sh_rstd = rstd;
         stats[((size_t)nb * G + g) * 2 + 0] = (float)mu;
         stats[((size_t)nb * G + g) * 2 + 1] = rstd;
     }
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {
-        const int gg = c / cpg;
-        const float sc = sh_rstd[gg] * gamma[c];
+    for (int i = tid; i < cpg; i += 256) {
+        const int c = g * cpg + i;
+        const float sc = sh_rstd * gamma[c];
         affine[((size_t)nb * 2 + 0) * C + c] = sc;
-        affine[((size_t)nb * 2 + 1) * C + c] = beta[c] - sh_mu[gg] * sc;
+        affine[((size_t)nb * 2 + 1) * C + c] = beta[c] - sh_mu * sc;
     }
-    (void)vpb;
 }
 
 // cond[nb, zv, 0, c] = by[c] + sum_j wy[c,j] zq[nb,zv,j];   cond[nb, zv, 1, c] = bb[c] + sum_j wb[c,j] zq[nb,zv,j]
@@ -228,7 +225,7 @@ extern "C" int aether_groupnorm_stats(const void* x, int NB, int V, int C, int G
     hipLaunchKernelGGL(groupnorm_partial_kernel, dim3(nblk_eff, NB), dim3(GN_PT), 0, AE_STREAM, (const unsigned short*)x, V, C, vpb, partial_ws);
     int rc = aether_check_launch("groupnorm_partial");
     if (rc) return rc;
-    hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(NB), dim3(256), 0, AE_STREAM, partial_ws, nblk_eff, C, G, V, vpb, eps, gamma, beta,
+    hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(G, NB), dim3(256), 0, AE_STREAM, partial_ws, nblk_eff, C, G, V, eps, gamma, beta,
                        stats, affine);
     return aether_check_launch("groupnorm_finalize");
 }

@@ -439,7 +439,6 @@ class AetherVAE:
     def _decode_chunk(self, z: torch.Tensor, crops, t0, T, H, W, first, cache):
         d = self.dec
         NB = len(crops)
-        zc = self.config.latent_channels
         # channels-last latent volume of this chunk (SpatialNorm3D conditions every norm on it)
         zq = torch.stack([z[:, t0:t0 + T, y0:y0 + H, x0:x0 + W] for (y0, x0) in crops], 0).permute(0, 2, 3, 4, 1).contiguous()
         A = self._im2col(z, d.conv_in, crops, t0, T, H, W, first)
@@ -460,7 +459,6 @@ class AetherVAE:
                 x = self._conv(vol, blk.up, (Tn, 2 * Hx, 2 * Wx), stride=1)
         x = self._causal_conv(x, d.norm_out, d.conv_out, cache, "decoder.conv_out", True, zq, None, 1e-6)
         return x[..., : self.config.out_channels]              # [NB, T_out, H_out, W_out, 3]
-        _ = zc
 
     # ------------------------------------------------------------------------------------------------
     @staticmethod

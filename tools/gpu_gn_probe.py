@@ -3,7 +3,6 @@ call and effective HBM rate (algorithmic bytes: partial = one read; apply = one 
 import json
 import os
 import sys
-import time
 
 import torch
 

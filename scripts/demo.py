@@ -29,6 +29,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from aether.pipelines.aetherv1_pipeline_cogvideox import AetherV1PipelineCogVideoX  # noqa: E402
+from aether_amd.export import colorize_depth, flip_for_export, output_stem, write_video  # noqa: E402
 from aether_amd.windows import WindowResult, blend_and_merge_window_results, get_window_starts, run_windows  # noqa: E402
 
 
@@ -143,16 +144,19 @@ def merge(args, results):
                                           smooth_camera=args.smooth_camera, smooth_method=args.smooth_method)
 
 
-def save_output(args, **arrays):
+def save_output(args, rgb, disparity, poses=None, pointmap=None, **extra):
+    """D:425-521: <output_dir>/<task>_<input name>_rgb.mp4 and _disparity.mp4 (colour-mapped); every array (point maps and
+    poses with the reference's export flips) additionally goes into <...>.npz.  The GLB scenes need trimesh (absent here)."""
     os.makedirs(args.output_dir, exist_ok=True)
-    name = {"reconstruction": args.video, "prediction": args.image, "planning": args.image}[args.task] or "output"
-    stem = os.path.splitext(os.path.basename(os.path.normpath(name)))[0]
-    out = os.path.join(args.output_dir, f"{args.task}_{stem}_seed{args.seed}.npz")
-    np.savez_compressed(out, **{k: v for k, v in arrays.items() if v is not None})
-    rgb = arrays.get("rgb")
-    if rgb is not None:
-        PIL.Image.fromarray((np.clip(rgb[0], 0, 1) * 255).astype(np.uint8)).save(out.replace(".npz", "_frame0.png"))
-    print(f"Saved outputs to {out}")
+    filename = os.path.join(args.output_dir, output_stem(args.task, args.video, args.image, args.goal))
+    arrays = dict(rgb=rgb, disparity=disparity, **{k: v for k, v in extra.items() if v is not None})
+    if pointmap is not None and poses is not None:
+        arrays["pointmap"], arrays["poses"] = flip_for_export(pointmap, poses)
+    np.savez_compressed(f"{filename}.npz", **arrays)
+    written = [f"{filename}.npz",
+               write_video(f"{filename}_rgb.mp4", (np.clip(rgb, 0, 1) * 255).astype(np.uint8), fps=12),
+               write_video(f"{filename}_disparity.mp4", (colorize_depth(disparity) * 255).astype(np.uint8), fps=12)]
+    print("Saved outputs to " + ", ".join(written))
 
 
 def main(argv=None) -> None:

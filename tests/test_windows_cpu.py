@@ -94,3 +94,31 @@ def test_gloo_world2_gather_is_bit_identical(tmp_path, frames):
     assert list(a["starts"]) == list(b["starts"]) and len(a["starts"]) >= 4
     for k in ("rgb", "disparity", "raymap"):
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_export_names_colour_map_and_flips(tmp_path):
+    """save_output's pieces (D:425-521): file stems, colorize_depth against the reference's own output, the export flips."""
+    from types import SimpleNamespace
+    from aether_amd.export import colorize_depth, flip_for_export, output_stem
+    assert output_stem("reconstruction", "assets/example_videos/moviegen.mp4", None, None) == "reconstruction_moviegen"
+    assert output_stem("prediction", None, "assets/example_obs/car.png", None) == "prediction_car"
+    assert output_stem("planning", None, "a/01_obs.png", "b/01_goal.v2.png") == "planning_01_obs_01_goal"
+    z = np.load(os.path.join(ROOT, "tests", "golden", "export.npz"))
+    assert np.array_equal(colorize_depth(z["disparity"]), z["colorized"])
+    rng = np.random.default_rng(0)
+    pm, poses = rng.random((2, 3, 4, 3)), rng.random((2, 4, 4))
+    fpm, fposes = flip_for_export(pm, poses)
+    assert np.array_equal(fpm, pm * np.array([-1, -1, 1.0]))
+    sign = np.array([[1, 1, -1, -1], [1, 1, -1, -1], [-1, -1, 1, 1], [1, 1, 1, 1.0]])      # rows and columns 0, 1 negated, then t_x, t_y
+    assert np.array_equal(fposes, poses * sign)
+    # the CLI's writer: every array in one .npz under the reference's stem, the videos as mp4 (imageio) or first-frame PNGs
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import importlib
+    demo = importlib.import_module("demo")
+    args = SimpleNamespace(output_dir=str(tmp_path), task="prediction", video=None, image="x/car.png", goal=None)
+    rgb, disp = rng.random((2, 6, 8, 3)).astype(np.float32), (0.1 + rng.random((2, 6, 8))).astype(np.float32)
+    demo.save_output(args, rgb=rgb, disparity=disp, poses=poses, pointmap=rng.random((2, 6, 8, 3)), raymap=None)
+    out = np.load(tmp_path / "prediction_car.npz")
+    assert set(out.files) == {"rgb", "disparity", "pointmap", "poses"} and np.array_equal(out["poses"], fposes)
+    assert any(f.name.startswith("prediction_car_rgb") for f in tmp_path.iterdir())
+    assert any(f.name.startswith("prediction_car_disparity") for f in tmp_path.iterdir())

@@ -49,6 +49,10 @@ def main():
                         rec_poses=rec_poses, fov_x=np.asarray(fov_x), fov_y=np.asarray(fov_y))
     make_blend_golden(U)
     make_eval_golden(U)
+    # --- colorize_depth (postprocess_utils.py:49-56), the colour map of the disparity video ---------------------------------
+    d = (np.random.default_rng(5).random((3, 6, 8)) * 0.9).astype(np.float32)
+    d[0, 0, 0] = 0.0
+    np.savez_compressed(os.path.join(OUT, "export.npz"), disparity=d, colorized=U.colorize_depth(d))
     print("wrote", os.listdir(OUT))
 
 

@@ -243,10 +243,10 @@ def smooth_trajectory(poses: np.ndarray, window_size: int = 5) -> np.ndarray:
 # ---- disparity -> point map ---------------------------------------------------------------------------------------------
 def postprocess_pointmap(disparity: np.ndarray, raymap: np.ndarray, vae_downsample_scale: int = 8,
                          camera_pose: Optional[np.ndarray] = None, focal=None, ray_o_scale_inv: float = 1.0,
-                         smooth_camera: bool = False, smooth_method: str = "simple") -> dict:
+                         smooth_camera: bool = False, smooth_method: str = "simple", with_pointmap: bool = True) -> dict:
     """U:283-351.  disparity [T,H,W] in [0,1], raymap [T,6,H/8,W/8] -> pointmap = depth * ray_d + ray_o (world space),
-    depth = 1 / clip(disparity, 1e-3, 1).  `raymap` is decoded in place by raymap_to_poses (see there)."""
-    depth = np.clip(1.0 / np.clip(disparity, 1e-3, 1), 0, 1e8)
+    depth = 1 / clip(disparity, 1e-3, 1).  `raymap` is decoded in place by raymap_to_poses (see there).
+    `with_pointmap=False` returns only camera_pose / intrinsics (callers that need just the cameras skip the per-pixel work)."""
     camera_pose, fov_x, fov_y = raymap_to_poses(raymap, camera_pose=camera_pose, ray_o_scale_inv=ray_o_scale_inv,
                                                 return_intrinsics=(focal is not None))
     H, W = int(raymap.shape[2] * vae_downsample_scale), int(raymap.shape[3] * vae_downsample_scale)
@@ -260,6 +260,9 @@ def postprocess_pointmap(disparity: np.ndarray, raymap: np.ndarray, vae_downsamp
             camera_pose = smooth_poses(camera_pose, window_size=5, method="gaussian")
         elif smooth_method == "kalman":
             camera_pose = smooth_trajectory(camera_pose, window_size=5)
+    if not with_pointmap:
+        return {"camera_pose": camera_pose, "intrinsics": get_intrinsics(camera_pose.shape[0], H, W, focal=focal)[0]}
+    depth = np.clip(1.0 / np.clip(disparity, 1e-3, 1), 0, 1e8)
     ray_o, ray_d, K = get_rays(camera_pose, H, W, focal)
     return {"pointmap": depth[..., None] * ray_d + ray_o, "camera_pose": camera_pose, "intrinsics": K, "ray_o": ray_o,
             "ray_d": ray_d, "depth": depth}

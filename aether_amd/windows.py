@@ -99,16 +99,21 @@ def run_windows(call_window: Callable[[int], "object"], starts: Sequence[int], g
 
 
 def blend_and_merge_window_results(results: Sequence[WindowResult], *, height: int, width: int, align_pointmaps: bool = False,
-                                   smooth_camera: bool = True, smooth_method: str = "kalman"):
+                                   smooth_camera: bool = True, smooth_method: str = "kalman", device: Optional[torch.device] = None):
     """The reference's sequential merge of overlapping windows (D:254-422), on the host in float64 like the reference:
     window k is brought into the frame of everything merged so far — disparity by a least-squares scale over the overlap
     (pixels with disparity > 0.1), camera poses by a similarity fitted on the overlapping cameras, focal lengths by their mean
     ratio — and cross-faded linearly over the overlap (poses by slerp); finally every frame is back-projected to a world-space
     point map.  Returns (rgb [N,H,W,3], disparity [N,H,W], poses [N,4,4], pointmaps [N,H,W,3]).
     Reference quirks kept on purpose: windows' raymaps are decoded in place (geometry.raymap_to_poses); the aligned poses of
-    windows k >= 1 carry the similarity's scale in element [3,3] outside the overlap (apply_transformation on 4x4 inputs)."""
+    windows k >= 1 carry the similarity's scale in element [3,3] outside the overlap (apply_transformation on 4x4 inputs).
+    `device`: run the per-pixel part (scale fit, cross-fades, back-projection: SURVEY.md §8f-2) as float64 torch operations on
+    that device instead of numpy on the host (`_merge_on_device`); the ≤ 41-pose camera algebra stays on the host either way."""
     from . import geometry as G
 
+    if device is not None and not align_pointmaps:
+        return _merge_on_device(results, height=height, width=width, smooth_camera=smooth_camera, smooth_method=smooth_method,
+                                device=torch.device(device))
     sm = smooth_method if smooth_camera else "none"
     first = results[0]
     n_win = first.rgb.shape[0]
@@ -123,7 +128,7 @@ def blend_and_merge_window_results(results: Sequence[WindowResult], *, height: i
     pointmaps = np.empty((total, *frame_shape, 3)) if align_pointmaps else None
     rgb[:n_win], disp[:n_win] = first.rgb, first.disparity
     pm0 = G.postprocess_pointmap(first.disparity, first.raymap, vae_downsample_scale=8, ray_o_scale_inv=0.1,
-                                 smooth_camera=smooth_camera, smooth_method=sm)
+                                 smooth_camera=smooth_camera, smooth_method=sm, with_pointmap=align_pointmaps)
     poses[:n_win] = pm0["camera_pose"]
     focals[:n_win] = (pm0["intrinsics"][:, 0, 0] + pm0["intrinsics"][:, 1, 1]) / 2
     if align_pointmaps:
@@ -176,6 +181,81 @@ def blend_and_merge_window_results(results: Sequence[WindowResult], *, height: i
             pointmaps[i] = G.project(1 / np.clip(disp[i], 1e-8, 1e8), np.array([[f, 0, 0.5 * width], [0, f, 0.5 * height], [0, 0, 1]]),
                                      poses[i])
     return rgb, disp, poses, pointmaps
+
+
+def _merge_on_device(results: Sequence[WindowResult], *, height: int, width: int, smooth_camera: bool, smooth_method: str,
+                     device: torch.device):
+    """The per-pixel work of blend_and_merge_window_results (align_pointmaps=False) on `device`: same operations, dtypes and
+    order as the host path (float32 operands of the scale fit, float64 everything else), as torch tensors — a 192-frame clip
+    (8 windows) costs the host ≈ 21 s of float64 numpy after the windows' 13 s of GPU time; on the MI355X it is a few HBM passes.
+    One H2D copy per window result, one D2H copy of the merged arrays."""
+    from . import geometry as G
+
+    sm = smooth_method if smooth_camera else "none"
+    first = results[0]
+    n_win = first.rgb.shape[0]
+    H, W = first.disparity.shape[1:]
+    total = results[-1].start + results[-1].rgb.shape[0]
+    f64 = dict(dtype=torch.float64, device=device)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)  # noqa: E731
+    rgb = torch.empty((total, H, W, 3), **f64)
+    disp = torch.empty((total, H, W), **f64)
+    poses = np.empty((total, 4, 4))
+    focals = np.empty((total,))
+    rgb[:n_win], disp[:n_win] = up(first.rgb), up(first.disparity)
+    pm0 = G.postprocess_pointmap(first.disparity, first.raymap, vae_downsample_scale=8, ray_o_scale_inv=0.1,
+                                 smooth_camera=smooth_camera, smooth_method=sm, with_pointmap=False)
+    poses[:n_win] = pm0["camera_pose"]
+    focals[:n_win] = (pm0["intrinsics"][:, 0, 0] + pm0["intrinsics"][:, 1, 1]) / 2
+    end = n_win
+    for k in range(1, len(results)):
+        r, t0 = results[k], results[k].start
+        t1 = t0 + r.rgb.shape[0]
+        ov = results[k - 1].start + n_win - t0
+        assert end == t0 + ov
+        fade_h = np.linspace(1, 0, ov)
+        fade = torch.from_numpy(fade_h).to(device)
+        r_disp, r_rgb = up(r.disparity), up(r.rgb)
+        # scale fit: float32 operands and float32 sums like the reference's torch code (U:847-864)
+        p, t = r_disp[:ov].float(), disp[t0:end].float()
+        m = (p > 0.1).float()
+        den = float((m * p * p).sum())
+        scale = float((m * p * t).sum()) / den if den != 0 else 0.0
+        w_disp = scale * r_disp
+        disp[t0:end] = disp[t0:end] * fade[:, None, None] + w_disp[:ov] * (1 - fade[:, None, None])
+        disp[end:t1] = w_disp[ov:]
+        rgb[t0:end] = rgb[t0:end] * fade[:, None, None, None] + r_rgb[:ov] * (1 - fade[:, None, None, None])
+        rgb[end:t1] = r_rgb[ov:]
+        # cameras and focal lengths: a few dozen 4x4 matrices — host
+        w_poses, fov_x, fov_y = G.raymap_to_poses(r.raymap, ray_o_scale_inv=0.1)
+        aR, aT, aS = G.align_camera_extrinsics(w_poses[:ov], poses[t0:end])
+        w_aligned = G.apply_transformation(w_poses, aR, aT, aS)
+        for i in range(ov):
+            poses[t0 + i] = G.interpolate_poses(poses[t0 + i], w_aligned[i], fade_h[i])
+        poses[end:t1] = w_aligned[ov:]
+        w_focals = G.focals_from_fov(w_poses.shape[0], H, W, fov_x, fov_y)
+        w_focals = (focals[t0:end] / w_focals[:ov]).mean() * w_focals
+        focals[t0:end] = focals[t0:end] * fade_h + w_focals[:ov] * (1 - fade_h)
+        focals[end:t1] = w_focals[ov:]
+        end = t1
+
+    # back-projection (U:393-403): world = pose[:3,:4] · [K⁻¹ · (u+.5, v+.5, 1) · depth ; 1], pixel grid in float32 like the reference
+    v, u = torch.meshgrid(torch.arange(H, device=device), torch.arange(W, device=device), indexing="ij")
+    pix = torch.stack([u.reshape(-1) + 0.5, v.reshape(-1) + 0.5, torch.ones(H * W, device=device)], 0).float().double()   # [3, HW]
+    K = np.zeros((total, 3, 3))
+    K[:, 0, 0] = K[:, 1, 1] = focals
+    K[:, 0, 2], K[:, 1, 2], K[:, 2, 2] = 0.5 * width, 0.5 * height, 1.0
+    K_inv = torch.from_numpy(np.linalg.inv(K)).to(device)
+    P = torch.from_numpy(poses[:, :3, :4].copy()).to(device)
+    pointmaps = torch.empty((total, H, W, 3), **f64)
+    step = 16
+    for i in range(0, total, step):
+        j = min(i + step, total)
+        depth = (1 / disp[i:j].clamp(1e-8, 1e8)).reshape(j - i, 1, H * W)
+        cam = (K_inv[i:j] @ pix) * depth                                                         # [n, 3, HW]
+        world = P[i:j, :, :3] @ cam + P[i:j, :, 3:]                                               # [n, 3, HW]
+        pointmaps[i:j] = world.transpose(1, 2).reshape(j - i, H, W, 3)
+    return rgb.cpu().numpy(), disp.cpu().numpy(), poses, pointmaps.cpu().numpy()
 
 
 def blend_rgb(results: Sequence[WindowResult], total_frames: int) -> np.ndarray:

@@ -138,10 +138,11 @@ def read_video(path: str) -> np.ndarray:
     return v.astype(np.float32) / 255.0 if v.dtype == np.uint8 else v.astype(np.float32)
 
 
-def merge(args, results):
-    """D:633-639 / D:436-449: merged (rgb, disparity, poses, pointmaps) of one or more windows."""
+def merge(args, results, device=None):
+    """D:633-639 / D:436-449: merged (rgb, disparity, poses, pointmaps) of one or more windows; the per-pixel part runs on
+    `device` (the reference does it in float64 numpy on the host: ~20 s for a 192-frame clip)."""
     return blend_and_merge_window_results(results, height=args.height, width=args.width, align_pointmaps=args.align_pointmaps,
-                                          smooth_camera=args.smooth_camera, smooth_method=args.smooth_method)
+                                          smooth_camera=args.smooth_camera, smooth_method=args.smooth_method, device=device)
 
 
 def save_output(args, rgb, disparity, poses=None, pointmap=None, **extra):
@@ -218,7 +219,7 @@ def main(argv=None) -> None:
                 geo = pipeline(task="reconstruction", video=output.rgb, num_inference_steps=4, guidance_scale=1.0, use_dynamic_cfg=False,
                                generator=torch.Generator(device=device).manual_seed(args.seed), **common)
             # like the reference's save_output (D:436-449): a single window goes through the same merge to get poses / point maps
-            _, _, poses, pointmaps = merge(args, [WindowResult(0, output.rgb, geo.disparity, geo.raymap.copy())])
+            _, _, poses, pointmaps = merge(args, [WindowResult(0, output.rgb, geo.disparity, geo.raymap.copy())], device)
             save_output(args, rgb=output.rgb, disparity=geo.disparity, raymap=geo.raymap, poses=poses, pointmap=pointmaps)
     else:
         starts = get_window_starts(len(video), args.num_frames, args.sliding_window_stride)
@@ -231,7 +232,7 @@ def main(argv=None) -> None:
 
         results = run_windows(call_window, starts, gather_device=device)
         if results is not None:
-            rgb, disparity, poses, pointmaps = merge(args, results)
+            rgb, disparity, poses, pointmaps = merge(args, results, device)
             save_output(args, rgb=rgb, disparity=disparity, poses=poses, pointmap=pointmaps, window_starts=np.asarray(starts))
     if world > 1:
         import torch.distributed as dist

@@ -30,8 +30,10 @@ def _windows():
 @pytest.mark.parametrize("tag,kw", [("plain", dict(align_pointmaps=False, smooth_camera=False)),
                                     ("aligned", dict(align_pointmaps=True, smooth_camera=False)),
                                     ("smooth", dict(align_pointmaps=False, smooth_camera=True, smooth_method="simple"))])
-def test_blend_matches_reference(tag, kw):
-    rgb, disp, poses, pm = blend_and_merge_window_results(_windows(), height=H, width=W, **kw)
+@pytest.mark.parametrize("device", [None, "cpu"])     # None: host numpy; "cpu": the torch path that runs on the GPU in scripts/demo.py
+def test_blend_matches_reference(tag, kw, device):
+    rgb, disp, poses, pm = blend_and_merge_window_results(_windows(), height=H, width=W, device=device, **kw)
+    assert all(isinstance(a, np.ndarray) and a.dtype == np.float64 for a in (rgb, disp, poses, pm))
     assert rgb.shape == (19, H, W, 3) and disp.shape == (19, H, W) and poses.shape == (19, 4, 4) and pm.shape == (19, H, W, 3)
     _close(rgb, GOLD["plain_rgb"], f"{tag} rgb")
     _close(disp, GOLD[f"{tag}_disparity"], f"{tag} disparity")
@@ -105,3 +107,15 @@ def test_camera_pose_to_raymap_matches_reference_and_round_trips():
     full = G.camera_pose_to_raymap(poses32, np.tile(z["K"], (n, 1, 1)), vae_downsample=1)
     assert full.shape == (n, 6, 480, 720)
     np.testing.assert_allclose(0.5 * (full[:, :3, 3::8, 3::8] + full[:, :3, 4::8, 4::8]), ray[:, :3], atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_blend_on_the_gpu_matches_reference():
+    """The device merge on the MI355X (float64 torch kernels) against the reference's outputs."""
+    import torch
+    for tag, kw in (("plain", dict(smooth_camera=False)), ("smooth", dict(smooth_camera=True, smooth_method="simple"))):
+        rgb, disp, poses, pm = blend_and_merge_window_results(_windows(), height=H, width=W, device=torch.device("cuda:0"), **kw)
+        _close(rgb, GOLD["plain_rgb"], f"{tag} rgb")
+        _close(disp, GOLD[f"{tag}_disparity"], f"{tag} disparity")
+        _close(poses, GOLD[f"{tag}_poses"], f"{tag} poses")
+        _close(pm, GOLD[f"{tag}_pointmaps"], f"{tag} pointmaps")

@@ -32,8 +32,8 @@ def get_window_starts(total_frames: int, sliding_window_size: int, temporal_stri
 @dataclass
 class WindowResult:
     start: int
-    rgb: np.ndarray         # [F, H, W, 3] float32
-    disparity: np.ndarray   # [F, H, W]    float32
+    rgb: np.ndarray         # [F, H, W, 3] float32 (a torch tensor after run_windows(keep_on_device=True))
+    disparity: np.ndarray   # [F, H, W]    float32 (likewise)
     raymap: np.ndarray      # [F, 6, h, w] float32
 
 
@@ -47,11 +47,14 @@ def shard(items: Sequence, rank: int, world: int) -> List:
     return [x for i, x in enumerate(items) if i % world == rank]
 
 
-def run_windows(call_window: Callable[[int], "object"], starts: Sequence[int], gather_device: Optional[torch.device] = None
-                ) -> Optional[List[WindowResult]]:
+def run_windows(call_window: Callable[[int], "object"], starts: Sequence[int], gather_device: Optional[torch.device] = None,
+                keep_on_device: bool = False) -> Optional[List[WindowResult]]:
     """Runs `call_window(start)` (one pipeline call returning .rgb/.disparity/.raymap numpy arrays) for this rank's share of
     `starts`, then all_gathers the outputs.  Returns the complete, start-ordered list on rank 0 (None on other ranks).
-    Without an initialised process group it simply runs every window in order."""
+    Without an initialised process group it simply runs every window in order.
+    `keep_on_device`: after a gather, rgb / disparity of the results stay torch tensors on the gather device (views of the
+    gathered buffer) for `blend_and_merge_window_results(..., device=)` — no D2H + H2D round trip of 230 MB per window; the
+    raymaps (pose algebra runs on the host) are numpy either way."""
     dist = _dist()
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
     mine = shard(list(enumerate(starts)), rank, world)
@@ -88,12 +91,18 @@ def run_windows(call_window: Callable[[int], "object"], starts: Sequence[int], g
         return None
     results: List[Optional[WindowResult]] = [None] * len(starts)
     for g, gi in zip(gathered, gathered_idx):
-        g, gi = g.cpu().numpy(), gi.cpu().tolist()
+        gi = gi.cpu().tolist()
+        if not keep_on_device:
+            g = g.cpu().numpy()
         for slot, idx in enumerate(gi):
             if idx < 0:
                 continue
-            a, b, c = np.split(g[slot], np.cumsum(sizes)[:-1])
-            results[idx] = WindowResult(starts[idx], a.reshape(shapes[0]).copy(), b.reshape(shapes[1]).copy(), c.reshape(shapes[2]).copy())
+            if keep_on_device:
+                a, b, c = torch.split(g[slot], sizes)
+                results[idx] = WindowResult(starts[idx], a.view(shapes[0]), b.view(shapes[1]), c.view(shapes[2]).cpu().numpy().copy())
+            else:
+                a, b, c = np.split(g[slot], np.cumsum(sizes)[:-1])
+                results[idx] = WindowResult(starts[idx], a.reshape(shapes[0]).copy(), b.reshape(shapes[1]).copy(), c.reshape(shapes[2]).copy())
     assert all(r is not None for r in results)
     return results
 
@@ -197,7 +206,7 @@ def _merge_on_device(results: Sequence[WindowResult], *, height: int, width: int
     H, W = first.disparity.shape[1:]
     total = results[-1].start + results[-1].rgb.shape[0]
     f64 = dict(dtype=torch.float64, device=device)
-    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)  # noqa: E731
+    up = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))).to(device)  # noqa: E731
     rgb = torch.empty((total, H, W, 3), **f64)
     disp = torch.empty((total, H, W), **f64)
     poses = np.empty((total, 4, 4))

@@ -230,7 +230,7 @@ def main(argv=None) -> None:
                             num_inference_steps=args.num_inference_steps, guidance_scale=1.0, use_dynamic_cfg=False,
                             generator=torch.Generator(device=device).manual_seed(args.seed), **common)
 
-        results = run_windows(call_window, starts, gather_device=device)
+        results = run_windows(call_window, starts, gather_device=device, keep_on_device=not args.align_pointmaps)
         if results is not None:
             rgb, disparity, poses, pointmaps = merge(args, results, device)
             save_output(args, rgb=rgb, disparity=disparity, poses=poses, pointmap=pointmaps, window_starts=np.asarray(starts))

@@ -119,3 +119,12 @@ def test_blend_on_the_gpu_matches_reference():
         _close(disp, GOLD[f"{tag}_disparity"], f"{tag} disparity")
         _close(poses, GOLD[f"{tag}_poses"], f"{tag} poses")
         _close(pm, GOLD[f"{tag}_pointmaps"], f"{tag} pointmaps")
+
+
+def test_device_merge_accepts_gathered_tensors():
+    """run_windows(keep_on_device=True) hands rgb / disparity over as torch tensors: same merged values."""
+    import torch
+    wins = [WindowResult(w.start, torch.from_numpy(w.rgb), torch.from_numpy(w.disparity), w.raymap) for w in _windows()]
+    got = blend_and_merge_window_results(wins, height=H, width=W, smooth_camera=False, device="cpu")
+    ref = blend_and_merge_window_results(_windows(), height=H, width=W, smooth_camera=False, device="cpu")
+    assert all(np.array_equal(a, b) for a, b in zip(got, ref))

@@ -128,3 +128,28 @@ def test_device_merge_accepts_gathered_tensors():
     got = blend_and_merge_window_results(wins, height=H, width=W, smooth_camera=False, device="cpu")
     ref = blend_and_merge_window_results(_windows(), height=H, width=W, smooth_camera=False, device="cpu")
     assert all(np.array_equal(a, b) for a, b in zip(got, ref))
+
+
+def test_reference_import_paths_and_calling_conventions():
+    """`from aether.utils.postprocess_utils import ...` (scripts/demo.py:25-35, evaluation/*/launch_aether.py) resolves, the
+    camera-alignment helpers speak torch like the reference's, and give the reference's values."""
+    import torch
+    from aether.utils.postprocess_utils import (align_camera_extrinsics, apply_transformation, camera_pose_to_raymap, colorize_depth,  # noqa: F401
+                                                compute_scale, get_intrinsics, interpolate_poses, postprocess_pointmap, project,
+                                                raymap_to_poses, smooth_trajectory)
+    from aether.utils.preprocess_utils import imcrop_center
+    p_a, _, _ = raymap_to_poses(GOLD["raymap_1"].copy(), ray_o_scale_inv=0.1)
+    p_b, _, _ = raymap_to_poses(GOLD["raymap_0"].copy(), ray_o_scale_inv=0.1)
+    R, T, s = align_camera_extrinsics(torch.from_numpy(p_a[:4]), torch.from_numpy(p_b[-4:]))
+    assert isinstance(R, torch.Tensor) and R.shape == (1, 3, 3) and T.shape == (1, 3)
+    _close(R.numpy(), GOLD["unit_align_R"], "R", 1e-9)
+    _close(T.numpy(), GOLD["unit_align_T"], "T", 1e-9)
+    out = apply_transformation(torch.from_numpy(p_a), R, T, s, return_extri=True)
+    assert isinstance(out, torch.Tensor)
+    _close(out.numpy(), GOLD["unit_applied"], "applied", 1e-9)
+    aR, aT = apply_transformation(torch.from_numpy(p_a), R, T, s, return_extri=False)
+    assert aR.shape == (p_a.shape[0], 4, 3) and aT.shape == (p_a.shape[0], 4)
+    d1, d0 = GOLD["disparity_1"][:4].reshape(1, -1, W), GOLD["disparity_0"][-4:].reshape(1, -1, W)
+    assert abs(compute_scale(torch.from_numpy(d1), torch.from_numpy(d0), torch.from_numpy(d1 > 0.1)) - float(GOLD["unit_scale"])) < 1e-5
+    img = np.random.default_rng(0).random((50, 72, 3), dtype=np.float32)
+    assert imcrop_center([img], 480, 720)[0].shape == (48, 72, 3)

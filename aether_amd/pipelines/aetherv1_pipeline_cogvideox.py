@@ -280,11 +280,11 @@ class AetherV1PipelineCogVideoX(_PipelineBase):
         return self.video_processor.preprocess(frames, height, width)
 
     def _preprocess_frames_on_device(self, frames, height, width, dev):
-        """Same values as `_preprocess_image(...).to(dev, bfloat16)` for an [N,H,W,C] / [H,W,C] uint8 or float32 array whose
+        """Same values as `_preprocess_image(...).to(dev, bfloat16)` for an [N,H,W,C] / [H,W,C] uint8 / float32 / float64 array whose
         centred crop window (preprocess_utils.py:4-39) lies inside the frame and already has the target size: the cropped VIEW
         is uploaded once and /255, 2x-1 (fp32, the same two IEEE operations as the host path), NHWC->NCHW and the bf16 rounding
         run on the device instead of as four host passes over the clip.  Returns None when the fast path does not apply."""
-        if isinstance(frames, torch.Tensor) or frames.dtype not in (np.uint8, np.float32) or frames.ndim not in (3, 4):
+        if isinstance(frames, torch.Tensor) or frames.dtype not in (np.uint8, np.float32, np.float64) or frames.ndim not in (3, 4):
             return None
         arr = frames[None] if frames.ndim == 3 else frames
         top, left, ch, cw = crop_window(arr.shape[1], arr.shape[2], height, width)

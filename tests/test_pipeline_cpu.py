@@ -126,7 +126,9 @@ def test_device_preprocess_fast_path_matches_host_path(parts):
         slow = pipe._preprocess_image(arr, H, W).to(torch.bfloat16)
         assert fast.shape == slow.shape and torch.equal(fast, slow)
     assert pipe._preprocess_frames_on_device(g.random((2, H // 2, W // 2, 3), dtype=np.float32), H, W, dev) is None   # needs a resize
-    assert pipe._preprocess_frames_on_device(g.random((2, H, W, 3)), H, W, dev) is None                                # float64
+    f64 = g.random((2, H, W, 3))                                          # float64 clips (cv2.resize(...) / 255.0 in the evaluation loaders)
+    assert torch.equal(pipe._preprocess_frames_on_device(f64, H, W, dev), pipe._preprocess_image(f64, H, W).to(torch.bfloat16))
+    assert pipe._preprocess_frames_on_device(g.random((2, H, W, 3)).astype(np.float16), H, W, dev) is None            # other dtypes: host path
     assert pipe._preprocess_frames_on_device(torch.zeros(2, H, W, 3), H, W, dev) is None
 
 

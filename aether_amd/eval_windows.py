@@ -62,7 +62,9 @@ class DepthPlan:
 
 def plan_depth_windows(t: int, h: int, w: int, total_frames: int, spatial_overlap: Tuple[int, int] = (60, 90),
                        temporal_stride: int = 8) -> DepthPlan:
-    """EV:87-150.  `t, h, w` are the clip's dimensions, `total_frames` bounds the window length."""
+    """EV:87-150.  `t, h, w` are the clip's dimensions, `total_frames` bounds the window length.
+    Reference behaviour kept: the crop stride is `(extent - target) // (n - 1)`, so with three or more crops up to n - 2
+    trailing rows / columns are not covered and the merged disparity is that much smaller than the clip."""
     nf = max_window_frames(total_frames)
     n_h = 1 if h <= TARGET_H else math.ceil((h - TARGET_H) / (TARGET_H - spatial_overlap[0])) + 1
     n_w = 1 if w <= TARGET_W else math.ceil((w - TARGET_W) / (TARGET_W - spatial_overlap[1])) + 1

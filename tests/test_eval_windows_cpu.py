@@ -140,3 +140,41 @@ def test_depth_units_shard_over_ranks_gloo(tmp_path):
         assert r.returncode == 0, r.stderr[-3000:]
         outs.append(np.load(out))
     assert np.array_equal(outs[0]["rgb"], outs[1]["rgb"]) and np.array_equal(outs[0]["disparity"], outs[1]["disparity"])
+
+
+def test_window_plans_cover_everything():
+    """Size-independent properties of the plans: every frame and every pixel row/column is inside some unit, consecutive units
+    overlap by at least the reference's minimum (60 rows / 90 columns; one frame), unit shapes are what the pipeline accepts."""
+    from hypothesis import given, settings, strategies as st
+    from aether_amd.eval_windows import plan_depth_windows, pose_window_starts
+    from aether_amd.windows import get_window_starts
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.integers(17, 400), st.integers(480, 1500), st.booleans())
+    def depth(t, extent, horizontal):
+        h, w = (480, max(extent, 720)) if horizontal else (extent, 720)
+        p = plan_depth_windows(t, h, w, t)
+        assert p.window_frames in (17, 25, 33, 41) and len(p.units) == len(p.times) * len(p.crops)
+        assert p.times[0][0] == 0 and p.times[-1][1] == t and all(b - a == p.window_frames for a, b in p.times)
+        assert all(nb[0] < pa[1] for pa, nb in zip(p.times, p.times[1:]))                    # temporal windows overlap
+        ext, tgt, min_ov = (w, 720, 90) if p.horizontal else (h, 480, 60)
+        # reference quirk kept: the crop stride is floored, so up to len(crops) - 2 trailing rows / columns stay uncovered
+        assert p.crops[0][0] == 0 and ext - max(len(p.crops) - 2, 0) <= p.crops[-1][1] <= ext and all(b - a == tgt for a, b in p.crops)
+        assert all(pa[1] - nb[0] >= min_ov for pa, nb in zip(p.crops, p.crops[1:]))
+        assert all((u.t1 - u.t0, u.h1 - u.h0, u.w1 - u.w0) == (p.window_frames, 480, 720) for u in p.units)
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.integers(17, 600))
+    def pose(t):
+        starts, nf = pose_window_starts(t)
+        assert nf in (17, 25, 33, 41) and starts[0] == 0 and starts[-1] + nf == t and starts == sorted(set(starts))
+        assert all(b - a <= 32 and a + nf > b for a, b in zip(starts, starts[1:]))           # consecutive windows overlap
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.integers(41, 600), st.integers(1, 40))
+    def demo(n, stride):
+        starts = get_window_starts(n, 41, stride)
+        assert starts[0] == 0 and starts[-1] + 41 == n and starts == sorted(set(starts))
+        assert all(b - a <= stride for a, b in zip(starts, starts[1:]))
+
+    depth(); pose(); demo()

@@ -53,6 +53,7 @@ def main():
     d = (np.random.default_rng(5).random((3, 6, 8)) * 0.9).astype(np.float32)
     d[0, 0, 0] = 0.0
     np.savez_compressed(os.path.join(OUT, "export.npz"), disparity=d, colorized=U.colorize_depth(d))
+    make_pipeline_golden()
     print("wrote", os.listdir(OUT))
 
 
@@ -210,5 +211,218 @@ def make_eval_golden(U):
     np.savez_compressed(os.path.join(OUT, "eval_windows.npz"), **out)
 
 
+# ======================================================================================================================
+# The reference's OWN pipeline module (aether/pipelines/aetherv1_pipeline_cogvideox.py), executed here.
+# It cannot be imported as is (`diffusers` is absent), so a stub `diffusers` package is put into sys.modules
+# for the duration of the import: the three module classes are placeholders, `CogVideoXDPMScheduler` is this repo's scheduler
+# (the reference tests `isinstance(self.scheduler, CogVideoXDPMScheduler)`, P:902), `get_1d_rotary_pos_embed` / `randn_tensor`
+# are the published diffusers formulas (stated below), and the base class `CogVideoXImageToVideoPipeline` is the thin slice of
+# diffusers' pipeline base the reference touches (this repo's `_PipelineBase`).  Everything the reference file itself defines
+# — get_3d_rotary_pos_embed, get_resize_crop_region_for_grid, check_inputs, preprocess_inputs, prepare_latents (raymap
+# front-padding and packing), the denoise loop with dynamic CFG, the output post-processing — runs VERBATIM from
+# /root/reference; only its outputs are stored.
+# ======================================================================================================================
+def _get_1d_rotary_pos_embed(dim, pos, theta=10000.0, use_real=False, linear_factor=1.0, ntk_factor=1.0, repeat_interleave_real=True,
+                             freqs_dtype=None):
+    """diffusers.models.embeddings.get_1d_rotary_pos_embed, use_real=True / repeat_interleave_real=True branch."""
+    import torch
+    assert use_real and repeat_interleave_real and linear_factor == 1.0 and ntk_factor == 1.0
+    if isinstance(pos, int):
+        pos = torch.arange(pos)
+    if isinstance(pos, np.ndarray):
+        pos = torch.from_numpy(pos)
+    freqs = 1.0 / (theta ** (torch.arange(0, dim, 2, dtype=torch.float32, device=pos.device)[: (dim // 2)] / dim))
+    freqs = torch.outer(pos, freqs)
+    return freqs.cos().repeat_interleave(2, dim=1).float(), freqs.sin().repeat_interleave(2, dim=1).float()
+
+
+def import_reference_pipeline():
+    """Returns the reference's pipeline MODULE (its own source, executed against the stub diffusers described above)."""
+    import importlib
+    import torch
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if repo not in sys.path:
+        sys.path.append(repo)                       # aether_amd / oracle; the name `aether` must resolve to the REFERENCE
+    if sys.path[0] != REF:
+        sys.path.insert(0, REF)
+    for k in [k for k in sys.modules if k == "aether" or k.startswith("aether.")]:
+        del sys.modules[k]
+    from aether_amd.pipelines.aetherv1_pipeline_cogvideox import _PipelineBase
+    from aether_amd.scheduler import CogVideoXDPMScheduler, randn_tensor
+
+    class StubBase(_PipelineBase):
+        prompt_embeds_for_tests = None
+
+        def encode_prompt(self, prompt, negative_prompt=None, do_classifier_free_guidance=True, num_videos_per_prompt=1,
+                          prompt_embeds=None, **kw):
+            return type(self).prompt_embeds_for_tests.clone(), None
+
+    class BaseOutput:
+        pass
+
+    d = types.ModuleType("diffusers")
+    d.AutoencoderKLCogVideoX = d.CogVideoXTransformer3DModel = object
+    d.CogVideoXDPMScheduler = CogVideoXDPMScheduler
+    d.CogVideoXImageToVideoPipeline = StubBase
+    mods = {"diffusers": d, "diffusers.image_processor": types.ModuleType("diffusers.image_processor"),
+            "diffusers.models": types.ModuleType("diffusers.models"),
+            "diffusers.models.embeddings": types.ModuleType("diffusers.models.embeddings"),
+            "diffusers.utils": types.ModuleType("diffusers.utils"),
+            "diffusers.utils.torch_utils": types.ModuleType("diffusers.utils.torch_utils")}
+    mods["diffusers.image_processor"].PipelineImageInput = object
+    mods["diffusers.models.embeddings"].get_1d_rotary_pos_embed = _get_1d_rotary_pos_embed
+    mods["diffusers.utils"].BaseOutput = BaseOutput
+    mods["diffusers.utils.torch_utils"].randn_tensor = randn_tensor
+    saved = {k: sys.modules.get(k) for k in mods}
+    sys.modules.update(mods)
+    try:
+        ref = importlib.import_module("aether.pipelines.aetherv1_pipeline_cogvideox")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    assert ref.__file__.startswith(REF), ref.__file__
+    return ref, StubBase
+
+
+PIPE_H, PIPE_W, PIPE_F = 96, 240, 17    # the geometry of tests/test_pipeline_cpu.py (tiling composes exactly at 1/5 scale)
+
+
+def pipeline_parts():
+    """Small bf16 oracle modules shared by this generator and tests/test_reference_pins_cpu.py (seeded, deterministic)."""
+    import torch
+    from aether_amd.scheduler import CogVideoXDPMScheduler
+    from oracle.dit import DitConfig, OracleTransformer3D, init_random_ as init_dit
+    from oracle.vae import OracleVAE, VaeConfig, init_random_ as init_vae
+    tcfg = DitConfig(num_attention_heads=2, num_layers=1, text_embed_dim=64, time_embed_dim=32, max_text_seq_length=8,
+                     sample_width=PIPE_W // 8, sample_height=PIPE_H // 8, sample_frames=PIPE_F)
+    dit = init_dit(OracleTransformer3D(tcfg), seed=1).to(torch.bfloat16)
+    vcfg = VaeConfig(block_out_channels=(32, 64, 64, 64), layers_per_block=1, sample_height=PIPE_H, sample_width=PIPE_W)
+    vae = init_vae(OracleVAE(vcfg), seed=2).to(torch.bfloat16)
+    vae.enable_tiling()
+    vae.enable_slicing()
+    prompt = (torch.randn(1, 8, 64, generator=torch.Generator().manual_seed(9)) * 0.1).to(torch.bfloat16)
+    return dit, vae, CogVideoXDPMScheduler, prompt
+
+
+def pipeline_inputs():
+    g = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:PIPE_H, 0:PIPE_W]
+    video = np.stack([np.stack([0.5 + 0.5 * np.sin(0.1 * xx + 0.2 * t + c) * np.cos(0.07 * yy) for c in range(3)], -1)
+                      for t in range(PIPE_F)]).astype(np.float32) * 0.9 + 0.05 * g.random((PIPE_F, PIPE_H, PIPE_W, 3), dtype=np.float32)
+    raymap = np.random.default_rng(5).standard_normal((PIPE_F, 6, PIPE_H // 8, PIPE_W // 8)).astype(np.float32)
+    return video, raymap
+
+
+def pipeline_cases():
+    video, raymap = pipeline_inputs()
+    u8 = (video * 255).astype(np.uint8)
+    return {
+        "reconstruction": dict(task="reconstruction", video=video, fps=12, seed=42),
+        "reconstruction_fps24_u8": dict(task="reconstruction", video=u8, fps=24, seed=7, num_inference_steps=2),
+        "prediction": dict(task="prediction", image=video[0], raymap=raymap, fps=12, seed=1, num_inference_steps=3),
+        "prediction_noraymap": dict(task="prediction", image=video[0], fps=8, seed=2, num_inference_steps=2),
+        "planning": dict(task="planning", image=video[0], goal=video[-1], raymap=raymap, fps=12, seed=1, num_inference_steps=3),
+        "planning_static_cfg": dict(task="planning", image=u8[0], goal=u8[-1], fps=15, seed=3, num_inference_steps=2,
+                                    guidance_scale=2.0),
+    }
+
+
+def run_pipeline_case(pipe, kw, record):
+    """One pipeline call; `record` receives (latents, condition_latents) from prepare_latents, the rotary tables, and the
+    guidance scale in force at every scheduler step."""
+    import functools
+    import torch
+    kw = dict(kw)
+    seed = kw.pop("seed")
+    orig_prepare, orig_rope, orig_step = pipe.prepare_latents, pipe._prepare_rotary_positional_embeddings, pipe.scheduler.step
+
+    def prepare(*a, **k):
+        out = orig_prepare(*a, **k)
+        record["latents"], record["condition_latents"] = out[0].float().numpy().copy(), out[1].float().numpy().copy()
+        return out
+
+    def rope(*a, **k):
+        out = orig_rope(*a, **k)
+        record["rope_cos"], record["rope_sin"] = out[0].numpy().copy(), out[1].numpy().copy()
+        return out
+
+    @functools.wraps(orig_step)          # prepare_extra_step_kwargs inspects the signature (eta / generator)
+    def step(*a, **k):
+        record.setdefault("guidance", []).append(float("nan") if pipe.guidance_scale is None else float(pipe.guidance_scale))
+        return orig_step(*a, **k)
+
+    pipe.prepare_latents, pipe._prepare_rotary_positional_embeddings, pipe.scheduler.step = prepare, rope, step
+    try:
+        out = pipe(height=PIPE_H, width=PIPE_W, num_frames=PIPE_F, generator=torch.Generator().manual_seed(seed), **kw)
+    finally:
+        pipe.prepare_latents, pipe._prepare_rotary_positional_embeddings = orig_prepare, orig_rope
+        pipe.scheduler.step = orig_step
+    record["guidance"] = np.array(record["guidance"])
+    return out
+
+
+def make_pipeline_golden():
+    import torch
+    ref, StubBase = import_reference_pipeline()
+    out = {"torch_version": np.array(torch.__version__), "cpu_capability": np.array(torch.backends.cpu.get_cpu_capability())}
+
+    # --- module-level functions of the reference (P:25-163) ------------------------------------------------------------
+    rope_cases = [((30, 45), 45, 30, 11, 1.0), ((30, 45), 45, 30, 11, 0.5), ((30, 45), 45, 30, 5, 1.5), ((6, 15), 15, 6, 5, 12 / 8),
+                  ((20, 45), 45, 30, 3, 1.0), ((30, 30), 45, 30, 2, 12 / 15), ((7, 9), 45, 30, 4, 1.2)]
+    for i, (grid, bw, bh, frames, fps_factor) in enumerate(rope_cases):
+        crops = ref.get_resize_crop_region_for_grid(grid, bw, bh)
+        cos, sin = ref.get_3d_rotary_pos_embed(embed_dim=64, crops_coords=crops, grid_size=grid, temporal_size=frames,
+                                               fps_factor=fps_factor)
+        out[f"rope_{i}_args"] = np.array([grid[0], grid[1], bw, bh, frames, fps_factor], np.float64)
+        out[f"rope_{i}_crops"] = np.array(crops)
+        step = 7 if cos.shape[0] > 2000 else 1                          # full-size tables: every 7th token + float64 sums
+        out[f"rope_{i}_cos"], out[f"rope_{i}_sin"] = cos.numpy()[::step], sin.numpy()[::step]
+        out[f"rope_{i}_sums"] = np.array([cos.double().sum().item(), sin.double().sum().item()])
+    crop_in = [(h, w, tw, th) for h in (1, 7, 30, 31, 60) for w in (1, 9, 45, 46, 90) for (tw, th) in ((45, 30), (30, 45), (17, 17))]
+    out["crop_in"] = np.array(crop_in)
+    out["crop_out"] = np.array([np.array(ref.get_resize_crop_region_for_grid((h, w), tw, th)).ravel() for h, w, tw, th in crop_in])
+
+    # --- the whole pipeline class, with the small oracle modules in its three slots --------------------------------------
+    dit, vae, Sched, prompt = pipeline_parts()
+    StubBase.prompt_embeds_for_tests = prompt
+    pipe = ref.AetherV1PipelineCogVideoX(tokenizer=None, text_encoder=None, vae=vae, scheduler=Sched(), transformer=dit)
+    pipe.set_progress_bar_config(disable=True)
+    for name, kw in pipeline_cases().items():
+        rec = {}
+        res = run_pipeline_case(pipe, kw, rec)
+        out[f"pipe_{name}_rgb"] = res.rgb[::2, ::3, ::5]                 # a pixel lattice + float64 sums of the whole arrays
+        out[f"pipe_{name}_rgb_sum"] = np.array(res.rgb.sum(dtype=np.float64))
+        out[f"pipe_{name}_disparity"] = res.disparity[::2, ::3, ::5]
+        out[f"pipe_{name}_disparity_sum"] = np.array(res.disparity.sum(dtype=np.float64))
+        out[f"pipe_{name}_raymap"] = res.raymap
+        for k, v in rec.items():
+            if k.startswith("rope") and name != "reconstruction_fps24_u8":
+                continue                                                   # the tables are covered above; keep one in-pipeline case
+            out[f"pipe_{name}_{k}"] = v
+    # error strings of check_inputs as the reference raises them (P:362-449)
+    video, raymap = pipeline_inputs()
+    bad = {"task": dict(task="foo", image=video[0]), "none": dict(task="prediction"), "both": dict(task="prediction", image=video[0], video=video),
+           "recon_image": dict(task="reconstruction", image=video[0]), "goal": dict(task="prediction", image=video[0], goal=video[0]),
+           "video": dict(task="prediction", video=video), "div8": dict(task="prediction", image=video[0], height=60),
+           "frames": dict(task="prediction", image=video[0], num_frames=16), "fps": dict(task="prediction", image=video[0], fps=30),
+           "raymap_type": dict(task="prediction", image=video[0], raymap="x"),
+           "raymap_shape": dict(task="prediction", image=video[0], raymap=raymap[:5])}
+    for name, kw in bad.items():
+        kw.setdefault("height", PIPE_H); kw.setdefault("width", PIPE_W); kw.setdefault("num_frames", PIPE_F)
+        try:
+            pipe(**kw)
+            raise AssertionError(name)
+        except ValueError as e:
+            out[f"err_{name}"] = np.array(str(e))
+    np.savez_compressed(os.path.join(OUT, "pipeline.npz"), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "pipeline":
+        os.makedirs(OUT, exist_ok=True)
+        make_pipeline_golden()
+    else:
+        main()

@@ -59,6 +59,8 @@ SIGNATURES = {
     "aether_dit_create": (_vp, [C.POINTER(AetherDitConfig)]),
     "aether_dit_destroy": (None, [_vp]),
     "aether_dit_set_weight": (_i, [_vp, C.c_char_p, _vp]),
+    "aether_dit_set_pos_embedding": (_i, [_vp, _vp, _i]),
+    "aether_dit_set_flags": (_i, [_vp, _i]),
     "aether_dit_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "aether_dit_set_profile": (_i, [_vp, _i]),
     "aether_dit_get_profile": (_i, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]),

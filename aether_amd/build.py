@@ -22,6 +22,17 @@ def _sources():
     return sorted(CSRC.glob("*.hip"))
 
 
+def source_digest() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources and the C header: stamps profiles so that a summary taken from an
+    older build of the kernels is recognised as stale (bench.py's roofline.traffic, tools/summarize_rocprof.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(list(_sources()) + list(CSRC.glob("*.hpp")) + [CSRC.parent.parent / "include" / "aether_hip.h"]):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def _stale() -> bool:
     if not LIB.exists():
         return True

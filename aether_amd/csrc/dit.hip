@@ -14,6 +14,9 @@
 struct AetherDit {
     AetherDitConfig cfg;
     std::map<std::string, const void*> w;
+    bool weights_checked = false;     // every name of kRequired registered (re-evaluated after each set_weight, not per forward)
+    const void* pos_emb = nullptr;    // positional table added after the patch embedding: [pos_rows, D] bf16 (text rows first)
+    int pos_rows = 0;
     // optional per-kernel-class timing (hipEvents recorded on the launch stream around each enqueue)
     bool profile = false;
     std::vector<hipEvent_t> events;   // pairs (start, stop)
@@ -100,7 +103,25 @@ extern "C" void aether_dit_destroy(AetherDit* h) {
 extern "C" int aether_dit_set_weight(AetherDit* h, const char* name, const void* dev_ptr) {
     if (!h || !name) return aether_set_error(AETHER_ERR_ARG, "dit_set_weight: null argument");
     if (((uintptr_t)dev_ptr) & 15) return aether_set_error(AETHER_ERR_ALIGN, "dit_set_weight: pointer must be 16-byte aligned");
+    if (std::string(name) == "pos_emb")
+        return aether_set_error(AETHER_ERR_ARG, "dit_set_weight: the positional table carries a row count: use aether_dit_set_pos_embedding");
     h->w[name] = dev_ptr;
+    h->weights_checked = false;
+    return AETHER_OK;
+}
+
+extern "C" int aether_dit_set_pos_embedding(AetherDit* h, const void* table, int rows) {
+    if (!h) return aether_set_error(AETHER_ERR_ARG, "dit_set_pos_embedding: null handle");
+    if (((uintptr_t)table) & 15) return aether_set_error(AETHER_ERR_ALIGN, "dit_set_pos_embedding: pointer must be 16-byte aligned");
+    if ((table == nullptr) != (rows <= 0)) return aether_set_error(AETHER_ERR_ARG, "dit_set_pos_embedding: give a table and its row count, or (null, 0)");
+    h->pos_emb = table;
+    h->pos_rows = table ? rows : 0;
+    return AETHER_OK;
+}
+
+extern "C" int aether_dit_set_flags(AetherDit* h, int flags) {
+    if (!h) return aether_set_error(AETHER_ERR_ARG, "dit_set_flags: null handle");
+    h->cfg.flags = flags;
     return AETHER_OK;
 }
 
@@ -166,14 +187,19 @@ extern "C" int aether_dit_forward(AetherDit* h, const void* hidden, const void* 
     if (B < 1 || B > 8) return aether_set_error(AETHER_ERR_SHAPE, "dit_forward: 1 <= B <= 8");
     if (H % c.patch_size || W % c.patch_size) return aether_set_error(AETHER_ERR_SHAPE, "dit_forward: H, W must be multiples of patch_size");
     if (!rope_cos || !rope_sin) return aether_set_error(AETHER_ERR_ARG, "dit_forward: rotary tables are required");
-    for (const char* name : kRequired)
-        if (h->w.find(name) == h->w.end() || h->w[name] == nullptr) {
-            std::string msg = std::string("dit_forward: weight not registered: ") + name;
-            return aether_set_error(AETHER_ERR_ARG, msg.c_str());
-        }
-    if (c.use_pos_embedding && (h->w.find("pos_emb") == h->w.end() || !h->w["pos_emb"]))
-        return aether_set_error(AETHER_ERR_ARG, "dit_forward: use_pos_embedding set but pos_emb not registered");
+    if (!h->weights_checked) {
+        for (const char* name : kRequired)
+            if (h->w.find(name) == h->w.end() || h->w[name] == nullptr) {
+                std::string msg = std::string("dit_forward: weight not registered: ") + name;
+                return aether_set_error(AETHER_ERR_ARG, msg.c_str());
+            }
+        h->weights_checked = true;
+    }
     const Plan p = make_plan(c, B, F, H, W);
+    if (c.use_pos_embedding) {
+        if (!h->pos_emb) return aether_set_error(AETHER_ERR_ARG, "dit_forward: use_pos_embedding set but no table registered (aether_dit_set_pos_embedding)");
+        if (h->pos_rows < p.S) return aether_set_error(AETHER_ERR_SHAPE, "dit_forward: positional table has fewer rows than text + video tokens");
+    }
     if (workspace_bytes < p.total) return aether_set_error(AETHER_ERR_ARG, "dit_forward: workspace too small");
     if (((uintptr_t)workspace) & 255) return aether_set_error(AETHER_ERR_ALIGN, "dit_forward: workspace must be 256-byte aligned");
 
@@ -189,7 +215,7 @@ extern "C" int aether_dit_forward(AetherDit* h, const void* hidden, const void* 
 
     // ---- embeddings ------------------------------------------------------------------------------
     AE_TRY(aether_patchify(hidden, patch, B, F, c.in_channels, H, W, c.patch_size, stream));
-    const char* pos = c.use_pos_embedding ? W_("pos_emb") : nullptr;
+    const char* pos = c.use_pos_embedding ? (const char*)h->pos_emb : nullptr;
     for (int b = 0; b < B; ++b) {
         char* xb = x + (size_t)b * S * D * 2;
         AE_TRY(aether_gemm_bf16((const char*)text + (size_t)b * Nt * c.text_dim * 2, c.text_dim, W_("text_w"), c.text_dim, xb, D,

@@ -172,6 +172,61 @@ AE_DEV void fa_store(const f32x16 (&o)[2], float l_run, const FlashArgs& p, int 
     }
 }
 
+// ---- guarded static shift (the lock-step kernel's soft-max; exact, shift-invariant) -----------------------------------
+// Soft-max is invariant under ANY per-row shift c:  o = Σ exp2(s−c)·v / Σ exp2(s−c).  The online algorithm uses c = the
+// running maximum only to keep exp2 in range.  Here the shift of a row is a value m that is a TRUE score maximum of the tiles
+// on which it was last refreshed (so the row's largest term is ≥ 1: no underflow of the sums), and a tile may be
+// exponentiated against the un-refreshed m — no maximum, no subtraction (m enters through the C operand of the first QKᵀ
+// MFMA: sc = K·Qᵀ − m for free), no rescale — whenever a cheap bound proves exp2 cannot overflow on it:
+//     |s| ≤ ‖q‖·max_tile‖k‖  (Cauchy–Schwarz; max‖k‖² per 64-key tile comes from aether_qk_norm_rope)
+//     ‖q‖²·max‖k‖² ≤ (m + FA_SHIFT_SPAN)²  with  m + FA_SHIFT_SPAN > 0   ⇒   s − m ≤ FA_SHIFT_SPAN  for every key of the tile.
+// p ≤ 2^90 is a normal fp32 / bf16 number and the sums stay below 2^90 · S · max|v| << 2^127.  A tile that fails the test (the
+// first tile of every row, and any tile whose keys could exceed the span) takes the refresh path: tile maximum, m ← max,
+// conditional rescale of o and l — the classic online step.  The choice is per wave and per tile, wave-uniform, and changes
+// only speed: results are those of an exact soft-max in fp32 either way.  AETHER_ATTN_EXACT_MAX (no bound table) refreshes on
+// every tile.
+constexpr float FA_SHIFT_SPAN = 90.f;
+constexpr int FA_KMAX_SLOTS = 1024;   // per-tile bounds of one (batch, head) staged in LDS: S <= 65 536 (longer rows refresh every tile)
+
+AE_DEV float fa_row_norm2(const bf16x8 (&qf)[4]) {
+    float qn2 = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float q = (float)qf[ks][e]; qn2 += q * q; }
+    return (qn2 + __shfl_xor(qn2, 32, 64)) * FA_BOUND_SLACK;
+}
+
+AE_DEV float fa_tile_max(const f32x16 (&sc)[2]) {
+    float a = fmaxf(sc[0][0], sc[1][0]), b = fmaxf(sc[0][1], sc[1][1]);
+#pragma unroll
+    for (int r = 2; r < 16; r += 2) {
+        a = fmaxf(a, fmaxf(sc[0][r], sc[1][r]));          // v_max3_f32
+        b = fmaxf(b, fmaxf(sc[0][r + 1], sc[1][r + 1]));
+    }
+    a = fmaxf(a, b);
+    return fmaxf(a, __shfl_xor(a, 32, 64));
+}
+
+// exponentiate a score tile that already carries its shift; P fragments + partial row sum
+AE_DEV void fa_exp_tile(const f32x16 (&sc)[2], bf16x8 (&pf)[2][2], float& l_run) {
+    float psum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float pv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                pv[e] = __builtin_amdgcn_exp2f(sc[t][8 * s + e]);
+                psum[e & 3] += pv[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[t][s][e] = (__bf16)pv[e];
+        }
+    l_run += (psum[0] + psum[1]) + (psum[2] + psum[3]);
+}
+
 // =================================================================================================================
 // lock-step kernel: one barrier per KV tile, double-buffered LDS (32 KiB), 2 workgroups per CU
 // =================================================================================================================
@@ -181,7 +236,10 @@ AE_DEV void fa_store(const f32x16 (&o)[2], float l_run, const FlashArgs& p, int 
 template <bool WIDE_STORE, int NW, int PRIO = 1>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))   // <= 128 VGPRs: 16 waves per CU
 void flash_attn_fwd_kernel(FlashArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * FA_BUF];
+    // 2 x (K tile + V^T tile) + this workgroup's Q fragments (4 KiB per wave, lane-linear: conflict-free ds_read_b128).  Q lives in
+    // LDS, not in 16 registers per lane: the registers hold the soft-max shift vector instead (see below) and the kernel stays
+    // within the 128-register budget of 4 waves per SIMD without spilling.
+    __shared__ __attribute__((aligned(16))) char smem[2 * FA_BUF + NW * 4096 + FA_KMAX_SLOTS * 4];
     const FaLane L = fa_lane_setup();
     const int tid = threadIdx.x, hi = L.hi;
 
@@ -225,59 +283,86 @@ void flash_attn_fwd_kernel(FlashArgs p) {
     f32x16 o[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
-    float m_run = -INFINITY;  // running row maximum, log2 domain (shared by the two lanes of a row)
+    float m_run = 0.f;        // the row's current shift (log2 domain; both lanes of a row hold the same value)
     float l_run = 0.f;        // this lane's partial row sum
+    float thr2 = -1.f;        // (m_run + FA_SHIFT_SPAN)^2 when that base is positive, else -1: a tile passes iff qn2*kmax2 <= thr2
+    f32x16 negm;              // -m_run in all 16 elements: the C operand of the first QK^T MFMA of every tile
+#pragma unroll
+    for (int i = 0; i < 16; ++i) negm[i] = 0.f;
 
     const int nkv = (S + FA_KVBLK - 1) / FA_KVBLK;
     const bool ragged = (S & (FA_KVBLK - 1)) != 0;
     stage(0, 0);
-    const bool fast = fa_fast_ok(qf, p.kmax2, bh, p.Spad / FA_KVBLK);
+    const float qn2 = fa_row_norm2(qf);
+    char* const qs = smem + 2 * FA_BUF + L.wave * 4096 + L.lane * 16;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) *(bf16x8*)(qs + ks * 1024) = qf[ks];
+    // max||k||^2 of every KV tile of this (batch, head) -> LDS (the per-tile guard reads it with one broadcast ds_read_b32: a
+    // global load inside the loop would share vmcnt with the K/V DMA and serialise it)
+    float* const kms = (float*)(smem + 2 * FA_BUF + NW * 4096);
+    const bool bounded = p.kmax2 != nullptr && nkv <= FA_KMAX_SLOTS;
+    if (bounded)
+        for (int i = tid; i < nkv; i += NW * 64) kms[i] = p.kmax2[(size_t)bh * (p.Spad / FA_KVBLK) + i];
     drain_and_barrier();
 
-    auto sweep = [&](auto fast_tag) {
-        constexpr bool FAST = decltype(fast_tag)::value;
-        for (int j = 0; j < nkv; ++j) {
-            const int cur = j & 1;
-            if (j + 1 < nkv) stage(j + 1, cur ^ 1);
-            const char* base = smem + cur * FA_BUF;
+    auto tile = [&](int j, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;     // the last tile: nothing to stage, ragged tail masked
+        const int cur = j & 1;
+        if (!LAST) stage(j + 1, cur ^ 1);
+        const char* base = smem + cur * FA_BUF;
+        const float km2 = bounded ? kms[j] : INFINITY;
 
-            f32x16 sc[2];
-            if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
+        f32x16 sc[2];
+        if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 qv = *(const bf16x8*)(qs + ks * 1024);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) sc[t][i] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const bf16x8 kf = *(const bf16x8*)(base + t * 4096 + L.koff[ks]);
-                    sc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[t], 0, 0, 0);
-                }
+                const bf16x8 kf = *(const bf16x8*)(base + t * 4096 + L.koff[ks]);
+                sc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qv, ks == 0 ? negm : sc[t], 0, 0, 0);
             }
-            if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
-            if (j == nkv - 1 && ragged) fa_mask_tail(sc, j, hi, S);
-
-            bf16x8 pf[2][2];
-            if (PRIO == 2) __builtin_amdgcn_s_setprio(1);
-            fa_softmax<FAST>(sc, pf, o, m_run, l_run);
-            if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
-
-            // ---- O^T += Vᵀ · Pᵀ ----
-            if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const bf16x8 vf = *(const bf16x8*)(base + dt * 4096 + L.voff[t][s]);
-                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[t][s], o[dt], 0, 0, 0);
-                    }
-            if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
-            drain_and_barrier();
         }
+        if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
+        if (LAST && ragged) fa_mask_tail(sc, j, hi, S);
+
+        if (__builtin_expect(!__all(qn2 * km2 <= thr2), 0)) {
+            // refresh (tile 0 of every row; otherwise rare): sc holds s - m_run; bring the shift up to this tile's maximum, in place
+            const float rel = fa_tile_max(sc);
+            const float up = (j == 0) ? rel : fmaxf(rel, 0.f);   // first tile: the shift becomes the tile's true maximum
+            if (__any(up != 0.f)) {
+                if (j > 0) {
+                    const float alpha = __builtin_amdgcn_exp2f(-up);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+                    l_run *= alpha;
+                }
+                m_run += up;
+                const float nb = m_run + FA_SHIFT_SPAN;
+                thr2 = nb > 0.f ? nb * nb : -1.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { sc[0][i] -= up; sc[1][i] -= up; negm[i] = -m_run; }
+            }
+        }
+        bf16x8 pf[2][2];
+        fa_exp_tile(sc, pf, l_run);                               // sc = s - m_run <= FA_SHIFT_SPAN (<= 0 after a refresh)
+
+        // ---- O^T += V^T . P^T ----
+        if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 vf = *(const bf16x8*)(base + dt * 4096 + L.voff[t][s]);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[t][s], o[dt], 0, 0, 0);
+                }
+        if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
+        if (!LAST) drain_and_barrier();
     };
-    if (fast) sweep(std::true_type{});
-    else sweep(std::false_type{});
+    for (int j = 0; j < nkv - 1; ++j) tile(j, std::false_type{});
+    tile(nkv - 1, std::true_type{});
 
     fa_store<WIDE_STORE>(o, l_run, p, bh, qrow, hi);
 }

@@ -202,6 +202,9 @@ class AetherV1PipelineCogVideoX(_PipelineBase):
     _default_use_dynamic_cfg = {"reconstruction": False, "prediction": True, "planning": True}
     _base_fps = 12
     _num_output_channels = 56  # 16 rgb + 16 disparity + 24 raymap latent channels (P:539, P:925-929)
+    # Extension (not in the reference): leave rgb / disparity / raymap as float32 torch tensors on the execution device — same
+    # values, no D2H copy — for callers that keep working on the GPU (sliding-window gather + merge, aether_amd/windows.py).
+    keep_outputs_on_device = False
 
     def __init__(self, tokenizer, text_encoder, vae, scheduler, transformer, empty_prompt_embeds: Optional[torch.Tensor] = None):
         super().__init__(tokenizer=tokenizer, text_encoder=text_encoder, vae=vae, scheduler=scheduler, transformer=transformer)
@@ -515,11 +518,16 @@ class AetherV1PipelineCogVideoX(_PipelineBase):
                 self.decode_latents(rgb_latents if self._cfg_rank == 0 else disparity_latents)).split(1)
         else:
             rgb_decoded, disparity_decoded = self.decode_latents(rgb_latents), self.decode_latents(disparity_latents)
-        rgb_video = self.video_processor.postprocess_video(video=rgb_decoded, output_type="np")
         disparity_video = disparity_decoded.mean(dim=1, keepdim=False)
-        disparity_video = torch.square(disparity_video * 0.5 + 0.5).float().cpu().numpy()
+        disparity_video = torch.square(disparity_video * 0.5 + 0.5).float()
+        if self.keep_outputs_on_device:
+            rgb_video = self.video_processor.postprocess_video(video=rgb_decoded, output_type="pt")          # [B,F,C,H,W], device
+            rgb_video = rgb_video.permute(0, 1, 3, 4, 2).float().contiguous()                                 # [B,F,H,W,C] like "np"
+        else:
+            rgb_video = self.video_processor.postprocess_video(video=rgb_decoded, output_type="np")
+            disparity_video = disparity_video.cpu().numpy()
         raymap_out = rearrange(camera_latents, "b t (n c) h w -> b (n t) c h w", n=4)[:, -rgb_video.shape[1]:, :, :]
-        raymap_out = raymap_out.float().cpu().numpy()
+        raymap_out = raymap_out.float() if self.keep_outputs_on_device else raymap_out.float().cpu().numpy()
         self.maybe_free_model_hooks()
         if not return_dict:
             return rgb_video, disparity_video, raymap_out

@@ -24,8 +24,26 @@ _CONFIG_DEFAULTS = dict(
     sample_height=60, sample_frames=41, temporal_compression_ratio=4, norm_eps=1e-5,
     use_rotary_positional_embeddings=True, use_learned_positional_embeddings=False, ofs_embed_dim=None,
     flip_sin_to_cos=True, freq_shift=0, activation_fn="gelu-approximate", timestep_activation_fn="silu",
-    attention_bias=True, norm_elementwise_affine=True,
+    attention_bias=True, norm_elementwise_affine=True, spatial_interpolation_scale=1.875, temporal_interpolation_scale=1.0,
 )
+
+
+def sincos_position_table(dim: int, n_text: int, frames: int, height: int, width: int, spatial_scale: float = 1.875,
+                          temporal_scale: float = 1.0) -> torch.Tensor:
+    """[n_text + frames*height*width, dim] float64: zeros for the text rows, then diffusers' get_3d_sincos_pos_embed for a
+    (height x width) patch grid — per token [temporal dim/4 | width 3dim/8 | height 3dim/8], each part [sin | cos] of
+    pos / 10000^(2i/d) with spatial positions divided by `spatial_scale`.  This is what diffusers' CogVideoXPatchEmbed adds
+    when the clip's frame count differs from `sample_frames` (it does NOT slice the learned table) [UPSTREAM-UNVERIFIED]."""
+    def axis(d, pos):
+        ang = torch.outer(pos.double(), 1.0 / 10000 ** (torch.arange(d // 2, dtype=torch.float64) / (d / 2.0)))
+        return torch.cat([ang.sin(), ang.cos()], dim=1)
+    dt, dsp = dim // 4, 3 * dim // 4
+    et = axis(dt, torch.arange(frames, dtype=torch.float32) / temporal_scale)          # [F, dt]
+    ew = axis(dsp // 2, torch.arange(width, dtype=torch.float32) / spatial_scale)      # [W, 3dim/8]
+    eh = axis(dsp // 2, torch.arange(height, dtype=torch.float32) / spatial_scale)     # [H, 3dim/8]
+    tab = torch.cat([et[:, None, None, :].expand(frames, height, width, dt), ew[None, None, :, :].expand(frames, height, width, dsp // 2),
+                     eh[None, :, None, :].expand(frames, height, width, dsp // 2)], dim=-1).reshape(frames * height * width, dim)
+    return torch.cat([torch.zeros(n_text, dim, dtype=torch.float64), tab], dim=0)
 
 
 class AetherTransformer3D:
@@ -58,6 +76,11 @@ class AetherTransformer3D:
             raise ValueError("aether_amd: only the rotary variant is implemented")
         if c.activation_fn != "gelu-approximate" or c.timestep_activation_fn != "silu":
             raise ValueError("aether_amd: unsupported activation")
+        # values the kernels hard-code (aether_timestep_sinusoid: [cos | sin], no frequency shift; biased linears; affine norms)
+        if not c.flip_sin_to_cos or c.freq_shift != 0:
+            raise ValueError("aether_amd: only flip_sin_to_cos=True, freq_shift=0 timestep features are implemented")
+        if not c.attention_bias or not c.norm_elementwise_affine:
+            raise ValueError("aether_amd: attention_bias=False / norm_elementwise_affine=False checkpoints are not supported")
 
     @property
     def inner_dim(self) -> int:
@@ -168,8 +191,36 @@ class AetherTransformer3D:
             raise ValueError("aether_dit_create: " + self._lib.aether_last_error().decode())
         self._handle = h
         self._weights = w
+        self._pos_tables = {}
+        self._pos_current = None
         for name, t in w.items():
+            if name == "pos_emb":
+                continue                      # chosen per call (`_select_pos_table`)
             _lib.check(self._lib.aether_dit_set_weight(h, name.encode(), t.data_ptr()), f"set_weight({name})")
+
+    def _select_pos_table(self, F: int, H: int, W: int):
+        """diffusers CogVideoXPatchEmbed.forward [UPSTREAM-UNVERIFIED, SURVEY.md A.1]: the learned table is used only at the
+        sample resolution AND `sample_frames` frames; at the sample resolution with another frame count (AetherV1's 41 frames on a
+        base with sample_frames 49) the 3-D sin-cos table of the actual size is added instead; another resolution raises."""
+        c = self.config
+        if not c.use_learned_positional_embeddings:
+            return
+        if (c.sample_height, c.sample_width) != (H, W):
+            raise ValueError("It is currently not possible to generate videos at a different resolution that the defaults. "
+                             "This should only be the case with 'THUDM/CogVideoX-5b-I2V'.")
+        key = "learned" if (F - 1) * c.temporal_compression_ratio + 1 == c.sample_frames else ("sincos", F)
+        if key not in self._pos_tables:
+            if key == "learned":
+                tab = self._weights["pos_emb"]
+            else:
+                p = c.patch_size
+                tab = sincos_position_table(self.inner_dim, c.max_text_seq_length, F, H // p, W // p, c.spatial_interpolation_scale,
+                                            c.temporal_interpolation_scale).to(device=self.device, dtype=torch.bfloat16).contiguous()
+            self._pos_tables[key] = tab
+        if self._pos_current != key:
+            tab = self._pos_tables[key]
+            _lib.check(self._lib.aether_dit_set_pos_embedding(self._handle, tab.data_ptr(), tab.shape[0]), "set_pos_embedding")
+            self._pos_current = key
 
     def init_random_weights(self, seed: int = 0, std: float = 0.02):
         """Seeded synthetic weights generated directly in HBM in the packed layout (benchmarks: real AetherV1
@@ -204,6 +255,11 @@ class AetherTransformer3D:
             w["pos_emb"] = mat(n_tok, D, fan_in=400)
         self._install(w)
         return self
+
+    def set_flags(self, flags: int):
+        """Replace the kernel flags (AETHER_GEMM_* | AETHER_ATTN_*) of the C handle, e.g. `| AETHER_ATTN_EXACT_MAX`."""
+        self._flags = flags
+        _lib.check(self._lib.aether_dit_set_flags(self._handle, int(flags)), "aether_dit_set_flags")
 
     def set_profile(self, enable: bool):
         """Bracket every kernel enqueue of the forward with HIP events on the launch stream (bench.py's roofline leg)."""
@@ -259,6 +315,7 @@ class AetherTransformer3D:
         n_vid = F * (H // c.patch_size) * (W // c.patch_size)
         if cos.shape != (n_vid, 64) or sin.shape != (n_vid, 64):
             raise ValueError(f"image_rotary_emb must be two [{n_vid},64] tensors, got {tuple(cos.shape)}")
+        self._select_pos_table(F, H, W)
         out = torch.empty(B, F, c.out_channels, H, W, dtype=torch.bfloat16, device=self.device)
         ws, need = self._get_workspace(B, F, H, W)
         rc = self._lib.aether_dit_forward(self._handle, x.data_ptr(), txt.data_ptr(), t.data_ptr(), cos.data_ptr(),

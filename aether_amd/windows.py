@@ -7,8 +7,8 @@ blended on the CPU, sequentially (D:254-422).  The reference runs the windows on
 
 Here windows are independent units: with one process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI on
 MI355X, "gloo" in the CPU tests) window w runs on rank w mod N, weights are replicated and nothing is exchanged during
-denoising.  The only collective is ONE all_gather of the finished per-window outputs (rgb 170 MB + disparity 57 MB +
-raymap 5 MB fp32 per window) so that rank 0 can run the sequential blend exactly as the reference does.  Results are
+denoising.  The only collective is ONE gather to rank 0 of the finished per-window outputs (rgb 170 MB + disparity 57 MB +
+raymap 5 MB fp32 per window, packed on the device) so that rank 0 can run the sequential blend exactly as the reference does.  Results are
 bit-identical to the single-process run for any N (same seeds, same per-window arithmetic, gather only moves data).
 """
 from __future__ import annotations
@@ -47,62 +47,71 @@ def shard(items: Sequence, rank: int, world: int) -> List:
     return [x for i, x in enumerate(items) if i % world == rank]
 
 
+def _as_tensor(a) -> torch.Tensor:
+    return a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+
+
 def run_windows(call_window: Callable[[int], "object"], starts: Sequence[int], gather_device: Optional[torch.device] = None,
-                keep_on_device: bool = False) -> Optional[List[WindowResult]]:
-    """Runs `call_window(start)` (one pipeline call returning .rgb/.disparity/.raymap numpy arrays) for this rank's share of
-    `starts`, then all_gathers the outputs.  Returns the complete, start-ordered list on rank 0 (None on other ranks).
-    Without an initialised process group it simply runs every window in order.
-    `keep_on_device`: after a gather, rgb / disparity of the results stay torch tensors on the gather device (views of the
-    gathered buffer) for `blend_and_merge_window_results(..., device=)` — no D2H + H2D round trip of 230 MB per window; the
-    raymaps (pose algebra runs on the host) are numpy either way."""
+                keep_on_device: bool = False, force_collective: bool = False) -> Optional[List[WindowResult]]:
+    """Runs `call_window(start)` (one pipeline call returning .rgb/.disparity/.raymap as numpy arrays or torch tensors) for this
+    rank's share of `starts`, then GATHERS the outputs on rank 0 (the only rank that merges).  Returns the complete, start-ordered
+    list on rank 0 (None on other ranks).  Without an initialised process group it simply runs every window in order.
+
+    The exchange is one `dist.gather(dst=0)` of a [windows-per-rank, 232 MB] fp32 payload per rank: under "nccl" (= RCCL, xGMI)
+    the payload is packed on the GPU from the pipeline's device-resident outputs (`pipeline.keep_outputs_on_device`) — no numpy
+    round trip — and only rank 0 receives (7 peer transfers of 232 MB per window instead of an all-gather to all 8 ranks); under
+    "gloo" (CPU tests) it is a CPU tensor.  `gather_device` defaults to the current CUDA device under nccl.
+    `keep_on_device`: rgb / disparity of the results stay torch tensors on the gather device (views of the gathered buffers) for
+    `blend_and_merge_window_results(..., device=)`; the raymaps (pose algebra runs on the host) are numpy either way.
+    `force_collective` runs the gather even in a one-rank group (lets a 1-GPU box exercise the RCCL path)."""
     dist = _dist()
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
     mine = shard(list(enumerate(starts)), rank, world)
     local = []
     for idx, s in mine:
         out = call_window(s)
-        local.append((idx, WindowResult(s, np.asarray(out.rgb, np.float32), np.asarray(out.disparity, np.float32),
-                                        np.asarray(out.raymap, np.float32))))
-    if dist is None or world == 1:
-        return [r for _, r in local]
+        local.append((idx, s, _as_tensor(out.rgb), _as_tensor(out.disparity), _as_tensor(out.raymap)))
 
-    # ---- one all_gather: every rank contributes ceil(n/world) slots (unused slots zero, index -1) -----------------
+    def result(s, rgb, disp, ray, dev_views):
+        if keep_on_device and dev_views:
+            return WindowResult(s, rgb, disp, ray.cpu().numpy().copy())
+        return WindowResult(s, rgb.cpu().numpy(), disp.cpu().numpy(), ray.cpu().numpy())
+
+    if dist is None or (world == 1 and not force_collective):
+        return [result(s, a, b, c, a.is_cuda) for _, s, a, b, c in local]
+
+    # ---- one gather to rank 0: every rank contributes ceil(n/world) slots (unused slots: index -1) ---------------------
     per_rank = (len(starts) + world - 1) // world
-    shapes = None
-    if local:
-        r0 = local[0][1]
-        shapes = (r0.rgb.shape, r0.disparity.shape, r0.raymap.shape)
+    shapes = (tuple(local[0][2].shape), tuple(local[0][3].shape), tuple(local[0][4].shape)) if local else None
     all_shapes = [None] * world
     dist.all_gather_object(all_shapes, shapes)
     shapes = next(s for s in all_shapes if s is not None)
     sizes = [int(np.prod(s)) for s in shapes]
-    dev = gather_device if (gather_device is not None and dist.get_backend() == "nccl") else torch.device("cpu")
-    payload = torch.zeros(per_rank, sum(sizes), dtype=torch.float32, device=dev)
+    if dist.get_backend() == "nccl":
+        dev = torch.device(gather_device) if gather_device is not None else torch.device("cuda", torch.cuda.current_device())
+    else:
+        dev = torch.device("cpu")
+    payload = torch.empty(per_rank, sum(sizes), dtype=torch.float32, device=dev)
     index = torch.full((per_rank,), -1, dtype=torch.int64, device=dev)
-    for slot, (idx, r) in enumerate(local):
-        flat = np.concatenate([r.rgb.ravel(), r.disparity.ravel(), r.raymap.ravel()])
-        payload[slot].copy_(torch.from_numpy(flat))
+    for slot, (idx, s, a, b, c) in enumerate(local):
+        torch.cat([a.reshape(-1).to(dev, torch.float32), b.reshape(-1).to(dev, torch.float32), c.reshape(-1).to(dev, torch.float32)],
+                  out=payload[slot])
         index[slot] = idx
-    gathered = [torch.empty_like(payload) for _ in range(world)]
-    gathered_idx = [torch.empty_like(index) for _ in range(world)]
-    dist.all_gather(gathered, payload)
-    dist.all_gather(gathered_idx, index)
+    if len(local) < per_rank:
+        payload[len(local):].zero_()
+    gathered = [torch.empty_like(payload) for _ in range(world)] if rank == 0 else None
+    gathered_idx = [torch.empty_like(index) for _ in range(world)] if rank == 0 else None
+    dist.gather(payload, gathered, dst=0)
+    dist.gather(index, gathered_idx, dst=0)
     if rank != 0:
         return None
     results: List[Optional[WindowResult]] = [None] * len(starts)
     for g, gi in zip(gathered, gathered_idx):
-        gi = gi.cpu().tolist()
-        if not keep_on_device:
-            g = g.cpu().numpy()
-        for slot, idx in enumerate(gi):
+        for slot, idx in enumerate(gi.cpu().tolist()):
             if idx < 0:
                 continue
-            if keep_on_device:
-                a, b, c = torch.split(g[slot], sizes)
-                results[idx] = WindowResult(starts[idx], a.view(shapes[0]), b.view(shapes[1]), c.view(shapes[2]).cpu().numpy().copy())
-            else:
-                a, b, c = np.split(g[slot], np.cumsum(sizes)[:-1])
-                results[idx] = WindowResult(starts[idx], a.reshape(shapes[0]).copy(), b.reshape(shapes[1]).copy(), c.reshape(shapes[2]).copy())
+            a, b, c = torch.split(g[slot], sizes)
+            results[idx] = result(starts[idx], a.view(shapes[0]), b.view(shapes[1]), c.view(shapes[2]), True)
     assert all(r is not None for r in results)
     return results
 

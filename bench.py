@@ -42,29 +42,36 @@ def flops_per_launch(cls: str, B: int, S: int, D: int, FF: int) -> float:
     }.get(cls, 0.0)
 
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_dit_step_v4.json")   # tools/profile_dit.sh + tools/summarize_rocprof.py
-
-
 def pmc_traffic(kernel_class: str, calls_per_forward: int = 42):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (FETCH_SIZE and WRITE_SIZE in separate passes; read side doubled per the gfx950 correction of
-    /opt/skills/guides/MI355X_MICROARCH.md §HBM; the write side is the raw counter).  None if no summary is committed."""
+    (tools/profile_dit.sh: FETCH_SIZE and WRITE_SIZE in separate passes; read side doubled per the gfx950 correction of
+    /opt/skills/guides/MI355X_MICROARCH.md §HBM; the write side is the raw counter).  Only a summary stamped with the digest
+    of the CURRENT kernel sources counts (tools/summarize_rocprof.py writes `csrc_sha16`): a profile of older kernels is
+    reported as stale -> (None, reason)."""
+    import glob
+
+    from aether_amd.build import source_digest
     needle = {"attention": "flash_attn", "gemm_qkv": "gemm_bf16_kernel<2, 4, 4, 2, 0", "gemm_ff1": "gemm_bf16_kernel<2, 4, 4, 2, 1",
               "gemm_ff2": "gemm_bf16_kernel<2, 4, 4, 2, 2", "gemm_out": "gemm_bf16_kernel<2, 4, 4, 2, 2"}.get(kernel_class)
-    try:
-        with open(PMC_SUMMARY) as f:
-            pmc = json.load(f)["pmc"]
-    except (OSError, KeyError, ValueError):
-        return None, None
-    # one logical launch may be several kernels (attention: 256-row workgroups + the 128-row tail launch): sum them
-    # (the PMC passes profile exactly one forward: `calls_per_forward` logical launches of the class = one per DiT block)
-    tot = 0.0
-    for name, e in pmc.items():
-        if needle and needle in name and "hbm_read_bytes_per_launch_corrected" in e:
-            tot += (e["hbm_read_bytes_per_launch_corrected"] + e.get("hbm_write_bytes_per_launch_raw", 0.0)) * e.get("launches", 1)
-    if tot == 0.0:
-        return None, None
-    return tot / calls_per_forward, os.path.relpath(PMC_SUMMARY, ROOT)
+    digest, stale = source_digest(), None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_dit_step*.json")), reverse=True):
+        try:
+            with open(path) as f:
+                doc = json.load(f)
+            pmc = doc["pmc"]
+        except (OSError, KeyError, ValueError):
+            continue
+        if doc.get("csrc_sha16") != digest:
+            stale = stale or os.path.relpath(path, ROOT)
+            continue
+        # one logical launch may be several kernels (tail launches): sum them; the PMC passes profile exactly one forward
+        tot = 0.0
+        for name, e in pmc.items():
+            if needle and needle in name and "hbm_read_bytes_per_launch_corrected" in e:
+                tot += (e["hbm_read_bytes_per_launch_corrected"] + e.get("hbm_write_bytes_per_launch_raw", 0.0)) * e.get("launches", 1)
+        if tot > 0.0:
+            return tot / calls_per_forward, os.path.relpath(path, ROOT)
+    return None, (f"stale: {stale} was taken from other kernel sources (digest now {digest})" if stale else "no PMC summary committed")
 
 
 def cpu_baseline(cfg_overrides, S_video_shape, seconds_budget=30.0):
@@ -90,6 +97,55 @@ def cpu_baseline(cfg_overrides, S_video_shape, seconds_budget=30.0):
     return {"value": steps_per_s, "unit": "denoise-steps/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"1 of {cfg.num_layers} DiT blocks at full size (B=1, S={n_vid + cfg.max_text_seq_length}, fp32 torch-CPU "
                       f"oracle, {dt:.1f} s), extrapolated x{cfg.num_layers}; host has {os.cpu_count()} logical cores"}
+
+
+def cpu_baseline_vae():
+    """fp32 oracle VAE (oracle/vae.py) on the host cores, bounded sample: ONE 240x360 tile x ONE 8-frame chunk of the encoder and
+    ONE 30x45 latent tile x ONE 2-latent-frame chunk of the decoder, extrapolated by the tile x chunk count of the 41x480x720
+    clip (9 tiles; 5.125 encoder chunks of 8 frames; 5.5 decoder chunks of 2 latent frames).  Baseline only."""
+    from oracle.vae import OracleVAE, VaeConfig, init_random_
+
+    vae = init_random_(OracleVAE(VaeConfig()), seed=1).float().eval()
+    with torch.no_grad():
+        x = torch.randn(1, 3, 8, 240, 360)
+        t0 = time.perf_counter()
+        vae.encoder(x)
+        te = time.perf_counter() - t0
+        z = torch.randn(1, 16, 2, 30, 45)
+        t0 = time.perf_counter()
+        vae.decoder(z)
+        td = time.perf_counter() - t0
+    return {"encode_s_per_clip": te * 9 * 41 / 8, "decode_s_per_clip": td * 9 * 11 / 2, "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"fp32 torch-CPU oracle: one 8x240x360 encoder tile-chunk ({te:.1f} s) x 46.1, one 2x30x45 decoder tile-chunk ({td:.1f} s) x 49.5"}
+
+
+def vae_leg(dev, reps=3):
+    """VAE encode of a 41x480x720 clip and decode of its 11x60x90 latent exactly as the pipeline calls them (tiling + slicing on):
+    seconds (HIP events on the launch stream), algorithmic TFLOP with the reference's tiling (175 / 369) and the
+    fraction of the 2.5 PF/s dense bf16 MFMA peak."""
+    from aether_amd.vae import AetherVAE
+
+    vae = AetherVAE(device=dev).init_random_weights(1)
+    vae.enable_slicing()
+    vae.enable_tiling()
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = (torch.rand(1, 3, 41, 480, 720, generator=g, device=dev) * 2 - 1).to(torch.bfloat16)
+    z = torch.randn(1, 16, 11, 60, 90, generator=g, device=dev).to(torch.bfloat16)
+    out = {}
+    for name, fn, tflop in (("encode", lambda: vae.encode(x).latent_dist.mode(), 175.0), ("decode", lambda: vae.decode(z).sample, 369.0)):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        sec = e0.elapsed_time(e1) * 1e-3 / reps
+        out[name] = {"seconds": sec, "algorithmic_tflop": tflop, "tflops": tflop / sec, "mfma_frac": tflop / sec / MFMA_PEAK_TFLOPS}
+    del vae
+    torch.cuda.empty_cache()
+    return out
 
 
 def clip_wall_clock(transformer, dev, steps):
@@ -127,6 +183,67 @@ def clip_wall_clock(transformer, dev, steps):
     return out
 
 
+def windows_mode(args, dev, rank, world, dist):
+    """BASELINE configs[4]: long-video reconstruction — 192 synthetic frames = 8 sliding 41-frame windows (stride 24, starts
+    0..144 + 151, scripts/demo.py:235-251), window w on rank w mod N, ONE gather of the device-resident outputs to rank 0
+    (RCCL; with N = 1 the same gather runs in a one-rank nccl group so the code path is exercised), merge on the device."""
+    import numpy as np
+
+    from aether.pipelines.aetherv1_pipeline_cogvideox import AetherV1PipelineCogVideoX
+    from aether_amd.scheduler import CogVideoXDPMScheduler
+    from aether_amd.transformer import AetherTransformer3D
+    from aether_amd.vae import AetherVAE
+    from aether_amd.windows import blend_and_merge_window_results, get_window_starts, run_windows
+
+    own_group = dist is None
+    if own_group:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    transformer = AetherTransformer3D({"num_layers": args.layers}, device=dev).init_random_weights(seed=0)
+    vae = AetherVAE(device=dev).init_random_weights(1)
+    vae.enable_slicing(); vae.enable_tiling()
+    g = torch.Generator().manual_seed(0)
+    prompt = (torch.randn(1, 226, 4096, generator=g) * 0.1).to(torch.bfloat16)
+    pipe = AetherV1PipelineCogVideoX(tokenizer=None, text_encoder=None, vae=vae, scheduler=CogVideoXDPMScheduler(),
+                                     transformer=transformer, empty_prompt_embeds=prompt)
+    pipe.set_progress_bar_config(disable=True)
+    pipe.keep_outputs_on_device = True
+    n_frames = 192
+    yy, xx = np.mgrid[0:480, 0:720].astype(np.float32)
+    video = np.stack([np.stack([0.5 + 0.4 * np.sin(0.02 * xx + 0.1 * t + c) * np.cos(0.015 * yy) for c in range(3)], -1)
+                      for t in range(n_frames)]).astype(np.float32)
+    starts = get_window_starts(n_frames, 41, 24)
+
+    def call_window(s0):
+        return pipe(task="reconstruction", video=video[s0:s0 + 41], height=480, width=720, num_frames=41,
+                    num_inference_steps=args.window_steps, fps=12, generator=torch.Generator(device=dev).manual_seed(42))
+
+    call_window(0)                                           # warm-up (allocations, first-touch)
+    dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    results = run_windows(call_window, starts, gather_device=dev, keep_on_device=True, force_collective=True)
+    torch.cuda.synchronize()
+    t_windows = time.perf_counter() - t0
+    if rank == 0:
+        rgb, disp, poses, pointmaps = blend_and_merge_window_results(results, height=480, width=720, device=dev)
+        torch.cuda.synchronize()
+        t_total = time.perf_counter() - t0
+        assert rgb.shape == (n_frames, 480, 720, 3) and np.isfinite(disp).all() and np.isfinite(pointmaps).all()
+        print(json.dumps({
+            "metric": "wall-clock per 192-frame 480x720 clip (8 sliding 41f windows + temporal blend)", "value": t_total, "unit": "s",
+            "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": t_total * 1e3, "higher_is_better": False, "scaling": "strong",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic (192 smooth frames; random-init weights)",
+            "config": {"workload": "configs[4]: long-video reconstruction, 8 windows x 41 frames, stride 24", "window_starts": starts,
+                       "sampler_steps_per_window": args.window_steps, "windows_per_rank": -(-len(starts) // world),
+                       "gather": f"dist.gather(dst=0) of device tensors, backend {dist.get_backend()}", "valid": args.layers == 42},
+            "seconds": {"windows_and_gather": t_windows, "merge_incl_d2h": t_total - t_windows}}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,7 +254,23 @@ def main():
     ap.add_argument("--no-clip", action="store_true", help="skip the end-to-end clip wall-clock leg (pipeline incl. VAE)")
     ap.add_argument("--clip-steps", type=int, default=50, help="sampler steps of the clip leg (reference default for reconstruction: 4)")
     ap.add_argument("--cfg", action="store_true", help="B=2 (prediction/planning CFG) instead of reconstruction B=1")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the attention-path legs and the VAE leg (profiling runs)")
+    ap.add_argument("--windows", action="store_true", help="BASELINE configs[4] end to end instead of the step benchmark: 192-frame clip, "
+                    "8 windows (stride 24) sharded over the ranks, gather to rank 0 over RCCL, device merge; reports s per clip")
+    ap.add_argument("--window-steps", type=int, default=4, help="sampler steps per window in --windows mode (reference default: 4)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # one process per GPU: re-launch this script under torch.distributed.run (the driver does this itself for N > 1)
+        import socket
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} HIP device(s) visible")
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -152,6 +285,8 @@ def main():
         dist = None
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
+    if args.windows:
+        return windows_mode(args, dev, rank, world, dist)
 
     from aether_amd.rope import resize_crop_region_for_grid, rotary_tables_3d
     from aether_amd.scheduler import CogVideoXDPMScheduler, randn_tensor
@@ -201,17 +336,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    model.set_profile(True)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = model.get_profile()
-    model.set_profile(False)
+    def timed(n_warm, n_steps):
+        for _ in range(n_warm):
+            step()
+        model.set_profile(True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        pr = model.get_profile()
+        model.set_profile(False)
+        return dt, pr
+
+    elapsed, prof = timed(args.warmup, args.steps)          # THE measurement: default flags, exactly --steps steps
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -237,19 +376,45 @@ def main():
             "mfma_frac_whole_step": steps_per_s / world * B * 260.8e12 / (MFMA_PEAK_TFLOPS * 1e12),
             "roofline": {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC)",
-                         "traffic_source": traffic_src, "avg_launch_ms": dom_ms / dom_n, "launches": dom_n,
+                         "traffic_source": traffic_src, "csrc_sha16": __import__("aether_amd.build", fromlist=["x"]).source_digest(), "avg_launch_ms": dom_ms / dom_n, "launches": dom_n,
                          "algorithmic_flops_per_launch": fl},
             "kernel_ms_per_step": {k: round(ms / args.steps, 3) for k, (ms, _) in prof.items()},
             "kernel_tflops": {k: round(flops_per_launch(k, B, S, D, FF) * n / (ms * 1e-3) / 1e12, 1) for k, (ms, n) in prof.items()
                               if flops_per_launch(k, B, S, D, FF) > 0 and ms > 0},
             "gpu_kernel_ms_per_step_total": total_ms / args.steps,
         }
+        if world == 1 and not args.no_extra_legs:
+            # The attention soft-max is exact on every path; what depends on the data is how often a tile may skip the shift
+            # refresh (include/aether_hip.h).  Two more measured legs bracket that: (a) refresh on EVERY tile
+            # (AETHER_ATTN_EXACT_MAX: the data-independent floor), (b) q/k-norm weights x3 (||q||·||k|| x9 ≈ 104 in the log2
+            # domain — beyond what round 1's whole-head gate admitted): the guard still passes after each row's first tile.
+            from aether_amd import _lib as L_
+            paths = {"default_guarded_shift": {"steps_per_s": steps_per_s, "attention_tflops": line["kernel_tflops"].get("attention")}}
+            fl0 = model._flags
+            model.set_flags(fl0 | L_.AETHER_ATTN_EXACT_MAX)
+            dt, pr = timed(1, args.steps)
+            paths["refresh_every_tile"] = {"steps_per_s": args.steps / dt,
+                                           "attention_tflops": round(flops_per_launch("attention", B, S, D, FF) * pr["attention"][1] / (pr["attention"][0] * 1e-3) / 1e12, 1)}
+            model.set_flags(fl0)
+            model._weights["qn_w"].mul_(3.0); model._weights["kn_w"].mul_(3.0)
+            dt, pr = timed(1, args.steps)
+            paths["qk_norm_gain_x3"] = {"steps_per_s": args.steps / dt,
+                                        "attention_tflops": round(flops_per_launch("attention", B, S, D, FF) * pr["attention"][1] / (pr["attention"][0] * 1e-3) / 1e12, 1)}
+            model._weights["qn_w"].div_(3.0); model._weights["kn_w"].div_(3.0)
+            line["attention_paths"] = paths
         if world == 1 and not args.no_clip:
             line["clip"] = clip_wall_clock(model, dev, args.clip_steps)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_extra_legs:
             del model
             torch.cuda.empty_cache()
+            line["vae"] = vae_leg(dev)
+        if world == 1 and not args.no_cpu_baseline:
+            model = None
+            torch.cuda.empty_cache()
             line["cpu_baseline"] = cpu_baseline({"num_layers": args.layers}, (F_, H_, W_))
+            line["cpu_baseline"]["covers"] = "the DiT steps only (>= 93 % of a 50-step clip); VAE: cpu_baseline_vae"
+            if not args.no_extra_legs:
+                line["cpu_baseline_vae"] = cpu_baseline_vae()
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -108,16 +108,21 @@ int aether_qk_norm_rope(const void* qkv, int B, int S, int H, int n_text, const 
 
 #define AETHER_ATTN_PIPELINED 16  /* flags bit 4: software-pipelined kernel (one workgroup per CU; inside each wave the soft-max
                                      of tile j is interleaved with the MFMAs of P·V(j-1) and K(j+1)·Qᵀ)                    */
-#define AETHER_ATTN_EXACT_MAX 32  /* flags bit 5: ignore kmax2, always run the exact online soft-max                      */
+#define AETHER_ATTN_EXACT_MAX 32  /* flags bit 5: ignore kmax2: the shift is refreshed (tile maximum, rescale) on EVERY tile   */
 #define AETHER_ATTN_TAIL_SPLIT 64 /* flags bit 6: workgroups beyond the last full round of 512 run as 128-row workgroups (2nd launch) */
 
 /* Non-causal flash attention, head_dim 64: O[b,s,h*64+d] = softmax_2(Qh·Khᵀ)·V where softmax_2 uses base 2, i.e.
  * Qh must carry softmax_scale·log2(e) (see aether_qk_norm_rope).  Replaces F.scaled_dot_product_attention in
  * CogVideoXAttnProcessor2_0.  Qh,Kh [B,H,S,64], Vt [B,H,64,Spad], O bf16 [B,S,H*64].
- * kmax2 (fp32 [B*H, Spad/64] or NULL): upper bound of ||k||^2 per (batch, head, 64-key tile).  A wave whose rows all satisfy
- * ||q||·sqrt(max over tiles of kmax2) <= 96 runs soft-max without the running maximum (scores are bounded, exp2 cannot overflow or
- * underflow, soft-max is shift invariant); every other wave, and every wave when kmax2 is NULL, runs the exact online
- * soft-max.  flags: AETHER_GEMM_WIDE_STORE (16-byte epilogue stores), AETHER_ATTN_*. */
+ * kmax2 (fp32 [B*H, Spad/64] or NULL): upper bound of ||k||^2 per (batch, head, 64-key tile).
+ * Soft-max (default, lock-step kernel) = exact, with a guarded static shift: each row keeps a shift m that is a true score
+ * maximum of the tiles it was last refreshed on (first tile always); a tile whose bound proves s - m <= 90 for all its keys
+ * (||q||^2·kmax2[tile] <= (m + 90)^2, m + 90 > 0) is exponentiated against m directly — no tile maximum, no subtraction (m
+ * rides in the C operand of the QK^T MFMA), no rescale; any other tile, and every tile when kmax2 is NULL or
+ * AETHER_ATTN_EXACT_MAX is set, takes the online step (tile maximum, shift update, rescale).  The choice is per wave and
+ * tile and changes only speed: soft-max is shift invariant, results are those of an exact fp32 soft-max either way.
+ * (The software-pipelined variant keeps the round-1 rule: no-maximum path iff ||q||·max||k|| <= 96 for the whole head.)
+ * flags: AETHER_GEMM_WIDE_STORE (16-byte epilogue stores), AETHER_ATTN_*. */
 int aether_flash_attn_fwd(const void* Qh, const void* Kh, const void* Vt, void* O, int B, int H, int S, int Spad,
                           const float* kmax2, int flags, void* stream);
 
@@ -211,6 +216,13 @@ void aether_dit_destroy(AetherDit* h);
 /* Register a device weight by its diffusers state-dict-derived name (see aether_amd/transformer.py for the
  * packing: fused qkv, concatenated AdaLN linears, fp32 biases/norm params).  Pointer must stay valid. */
 int aether_dit_set_weight(AetherDit* h, const char* name, const void* dev_ptr);
+/* Positional table added to the patch/text embedding when cfg.use_pos_embedding: bf16 [rows, D], text rows first
+ * (diffusers CogVideoXPatchEmbed: the learned `pos_embedding` when the clip has `sample_frames` frames, otherwise the
+ * 3-D sin-cos table of the actual size — the caller picks, aether_amd/transformer.py).  aether_dit_forward refuses a
+ * table with fewer rows than text + video tokens (no out-of-bounds read).  (NULL, 0) unregisters. */
+int aether_dit_set_pos_embedding(AetherDit* h, const void* table, int rows);
+/* Replace the AETHER_GEMM_* / AETHER_ATTN_* flags given at creation (e.g. AETHER_ATTN_EXACT_MAX for a measurement). */
+int aether_dit_set_flags(AetherDit* h, int flags);
 /* Bytes of scratch the forward needs for batch B and a latent grid F x H x W (latent pixels). */
 size_t aether_dit_workspace_bytes(const AetherDit* h, int B, int F, int H, int W);
 /* hidden bf16 [B,F,in_channels,H,W]; text bf16 [B,max_text_len,text_dim]; timesteps fp32 [B] (device);

@@ -49,6 +49,8 @@ class DitConfig:
     activation_fn: str = "gelu-approximate"
     timestep_activation_fn: str = "silu"
     attention_bias: bool = True
+    spatial_interpolation_scale: float = 1.875     # CogVideoXTransformer3DModel.__init__ defaults
+    temporal_interpolation_scale: float = 1.0
 
     @property
     def inner_dim(self) -> int:
@@ -87,6 +89,26 @@ class TimestepEmbedding(nn.Module):
         return self.linear_2(F.silu(self.linear_1(x)))
 
 
+def sincos_1d(dim: int, pos: torch.Tensor) -> torch.Tensor:
+    """diffusers get_1d_sincos_pos_embed_from_grid (float64, [sin | cos], flip_sin_to_cos=False)."""
+    omega = torch.arange(dim // 2, dtype=torch.float64) / (dim / 2.0)
+    omega = 1.0 / 10000 ** omega
+    out = torch.outer(pos.reshape(-1).double(), omega)
+    return torch.cat([torch.sin(out), torch.cos(out)], dim=1)
+
+
+def sincos_pos_embed_3d(dim: int, width: int, height: int, frames: int, spatial_scale: float, temporal_scale: float) -> torch.Tensor:
+    """diffusers get_3d_sincos_pos_embed(embed_dim, (width, height), frames, ...) -> [frames, height*width, dim]:
+    per token [temporal dim/4 | spatial 3dim/4], the spatial part = [emb(grid_w) | emb(grid_h)] (meshgrid 'xy', w first)."""
+    ds, dt = 3 * dim // 4, dim // 4
+    gh = torch.arange(height, dtype=torch.float32) / spatial_scale
+    gw = torch.arange(width, dtype=torch.float32) / spatial_scale
+    mw, mh = torch.meshgrid(gw, gh, indexing="xy")            # both [height, width]
+    spatial = torch.cat([sincos_1d(ds // 2, mw), sincos_1d(ds // 2, mh)], dim=1)          # [H*W, ds]
+    temporal = sincos_1d(dt, torch.arange(frames, dtype=torch.float32) / temporal_scale)   # [T, dt]
+    return torch.cat([temporal[:, None, :].expand(frames, height * width, dt), spatial[None].expand(frames, height * width, ds)], dim=-1)
+
+
 class PatchEmbed(nn.Module):
     """CogVideoXPatchEmbed, patch_size_t=None branch."""
 
@@ -109,10 +131,22 @@ class PatchEmbed(nn.Module):
         x = x.flatten(3).transpose(2, 3)   # [B, F, H*W/p^2, D]
         x = x.flatten(1, 2)                # token order (frame, row, col)
         embeds = torch.cat([text_embeds, x], dim=1).contiguous()
-        if self.cfg.use_learned_positional_embeddings:
-            if embeds.shape[1] != self.pos_embedding.shape[1]:
-                raise ValueError("learned positional embeddings need the sample-size token count")
-            embeds = embeds + self.pos_embedding.to(embeds.dtype)
+        cfg = self.cfg
+        if cfg.use_learned_positional_embeddings or not cfg.use_rotary_positional_embeddings:
+            # diffusers CogVideoXPatchEmbed.forward (0.32) [UPSTREAM-UNVERIFIED]: the learned table needs the sample resolution;
+            # when the FRAME count differs from sample_frames (AetherV1 runs 41 frames on a base whose sample_frames is 49)
+            # it does not slice the learned table: it recomputes the 3-D sin-cos table for the actual size and adds that.
+            if cfg.use_learned_positional_embeddings and (cfg.sample_width != W or cfg.sample_height != H):
+                raise ValueError("It is currently not possible to generate videos at a different resolution that the defaults.")
+            pre_frames = (Fr - 1) * cfg.temporal_compression_ratio + 1
+            if cfg.sample_height != H or cfg.sample_width != W or cfg.sample_frames != pre_frames or not cfg.use_learned_positional_embeddings:
+                p = cfg.patch_size
+                pe = sincos_pos_embed_3d(cfg.inner_dim, W // p, H // p, Fr, cfg.spatial_interpolation_scale, cfg.temporal_interpolation_scale)
+                pos = torch.zeros(1, cfg.max_text_seq_length + pe.shape[0] * pe.shape[1], cfg.inner_dim, dtype=pe.dtype)
+                pos[:, cfg.max_text_seq_length:] = pe.flatten(0, 1)
+            else:
+                pos = self.pos_embedding
+            embeds = embeds + pos.to(embeds.dtype)
         return embeds
 
 

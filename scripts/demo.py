@@ -230,6 +230,8 @@ def main(argv=None) -> None:
                             num_inference_steps=args.num_inference_steps, guidance_scale=1.0, use_dynamic_cfg=False,
                             generator=torch.Generator(device=device).manual_seed(args.seed), **common)
 
+        # window outputs never leave HBM between the pipeline, the gather to rank 0 (RCCL) and the device merge
+        pipeline.keep_outputs_on_device = not args.align_pointmaps
         results = run_windows(call_window, starts, gather_device=device, keep_on_device=not args.align_pointmaps)
         if results is not None:
             rgb, disparity, poses, pointmaps = merge(args, results, device)

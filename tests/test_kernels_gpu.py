@@ -336,6 +336,49 @@ def test_flash_attention_bound_gate(cuda, hip_lib, flags):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("pattern", ["hot_rows", "late_hot_keys", "early_peak", "cold_start", "span_edge"])
+@pytest.mark.parametrize("flags", [0, 1])
+def test_flash_attention_guarded_shift(cuda, hip_lib, flags, pattern):
+    """The lock-step kernel's soft-max keeps a per-row shift m (a true score maximum of the tiles it was refreshed on) and
+    exponentiates a tile against the un-refreshed m whenever ||q||·max_tile||k|| <= m + 90 proves exp2 cannot overflow; any
+    other tile takes the refresh (online) step.  Score ranges far beyond fp32's exp2 range, in every order, against an fp64
+    soft-max — with the per-tile bounds exactly as aether_qk_norm_rope emits them (max ||k||^2 per 64-key tile)."""
+    from aether_amd import ops
+    g = torch.Generator().manual_seed(sum(map(ord, pattern)))
+    B, H, S = 1, 2, 900
+    unit = lambda *sh: torch.nn.functional.normalize(torch.randn(*sh, generator=g), dim=-1)   # noqa: E731
+    q, k = unit(B, H, S, 64) * 8.0, unit(B, H, S, 64) * 8.0          # |s| <= 64 to start with
+    if pattern == "hot_rows":          # some query rows with ||q||·||k|| = 320: their waves refresh, the others never do
+        q[:, :, 300:400] *= 5.0
+    elif pattern == "late_hot_keys":   # keys of tiles 9..10 four times longer, aligned with some queries: +250 late in the sweep
+        k[:, :, 600:700] *= 4.0
+        k[:, :, 610] = q[:, :, 3] * 4.0
+        k[:, :, 650] = q[:, :, 500] * 4.0
+    elif pattern == "early_peak":      # the maximum (+256) sits in tile 0, everything later is ~2^-200 of it
+        k[:, :, 5] = q[:, :, 100] * 4.0
+        k[:, :, 9] = q[:, :, 700] * 4.0
+    elif pattern == "cold_start":      # tile 0 scores are all very negative for some rows (shift starts below -90), then normal keys
+        k[:, :, :64] = -q[:, :, 40:41] * 3.5 + 0.05 * torch.randn(B, H, 64, 64, generator=g)
+    elif pattern == "span_edge":       # bounds straddling the 90 span: ||q||·||k|| from 60 to 130 across tiles
+        k *= torch.linspace(0.9, 2.0, S).view(1, 1, S, 1)
+    v = torch.randn(B, H, S, 64, generator=g)
+    qb, kb, vb = q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
+    ref = (torch.softmax((qb.double() @ kb.double().transpose(-1, -2)) * math.log(2.0), dim=-1) @ vb.double()).float()
+    ref = ref.transpose(1, 2).reshape(B, S, H * 64)
+    Spad = (S + 63) // 64 * 64
+    vt = torch.zeros(B, H, 64, Spad, dtype=torch.bfloat16)
+    vt[..., :S] = vb.transpose(2, 3)
+    n2 = torch.zeros(B * H, Spad)
+    n2[:, :S] = (kb.float() ** 2).sum(-1).reshape(B * H, S)
+    kmax2 = n2.reshape(B * H, Spad // 64, 64).amax(-1).contiguous()
+    out = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags, kmax2=kmax2.to(cuda))
+    every = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags | 32, kmax2=kmax2.to(cuda))   # refresh on every tile
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    _bf16_close(out, ref, f"flash guarded shift {pattern}", rel=1.5e-2, max_ulp_frac=4.0)
+    _bf16_close(every, ref, f"flash refresh-every-tile {pattern}", rel=1.5e-2, max_ulp_frac=4.0)
+
+
 @pytest.mark.parametrize("flags", ATTN_FLAGS)
 def test_flash_attention_online_max_jump(cuda, hip_lib, flags):
     """Force the rescale branch late in the KV sweep: one key far larger than everything before it (guide rule 26)."""

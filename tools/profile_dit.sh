@@ -8,11 +8,12 @@ set -u
 NAME=${1:-prof_dit}
 OUT=gpurun_out/$NAME
 export TMPDIR=/tmp
-BENCH="python bench.py --no-clip --no-cpu-baseline"
+BENCH="python bench.py --no-clip --no-cpu-baseline --no-extra-legs"
 mkdir -p $OUT
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH --steps 2 --warmup 1 > $OUT/trace.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH --steps 1 --warmup 0 > $OUT/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH --steps 1 --warmup 0 > $OUT/pmc_write.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_sq -- $BENCH --steps 1 --warmup 0 > $OUT/pmc_sq.log 2>&1
+timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2 -- $BENCH --steps 1 --warmup 0 > $OUT/pmc_l2.log 2>&1
 grep -h '"metric"' $OUT/trace.log | cut -c1-400
 python tools/summarize_rocprof.py $OUT gpurun_out/${NAME}_summary

@@ -27,7 +27,9 @@ def short(name: str) -> str:
 
 
 def main(src: str, dst_prefix: str):
-    out = {"source": src, "kernel_stats": [], "pmc": {}}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from aether_amd.build import source_digest
+    out = {"source": src, "csrc_sha16": source_digest(), "kernel_stats": [], "pmc": {}}
     stats = glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True)
     if stats:
         with open(stats[0]) as f:
@@ -59,6 +61,8 @@ def main(src: str, dst_prefix: str):
             e["hbm_read_bytes_per_launch_corrected"] = e["FETCH_SIZE_avg_per_launch"] * 1024 * 2
         if "WRITE_SIZE_avg_per_launch" in e:
             e["hbm_write_bytes_per_launch_raw"] = e["WRITE_SIZE_avg_per_launch"] * 1024
+        if "TCC_HIT_sum_avg_per_launch" in e and "TCC_MISS_sum_avg_per_launch" in e:
+            e["l2_hit_rate"] = e["TCC_HIT_sum_avg_per_launch"] / max(e["TCC_HIT_sum_avg_per_launch"] + e["TCC_MISS_sum_avg_per_launch"], 1.0)
     os.makedirs(os.path.dirname(dst_prefix) or ".", exist_ok=True)
     with open(dst_prefix + ".json", "w") as f:
         json.dump(out, f, indent=1)

@@ -180,12 +180,12 @@ AE_DEV void fa_store(const f32x16 (&o)[2], float l_run, const FlashArgs& p, int 
 // MFMA: sc = K·Qᵀ − m for free), no rescale — whenever a cheap bound proves exp2 cannot overflow on it:
 //     |s| ≤ ‖q‖·max_tile‖k‖  (Cauchy–Schwarz; max‖k‖² per 64-key tile comes from aether_qk_norm_rope)
 //     ‖q‖²·max‖k‖² ≤ (m + FA_SHIFT_SPAN)²  with  m + FA_SHIFT_SPAN > 0   ⇒   s − m ≤ FA_SHIFT_SPAN  for every key of the tile.
-// p ≤ 2^90 is a normal fp32 / bf16 number and the sums stay below 2^90 · S · max|v| << 2^127.  A tile that fails the test (the
+// p ≤ 2^100 is a normal fp32 / bf16 number and the sums stay below 2^100 · S · max|v| < 2^127 for S·max|v| < 2^27.  A tile that fails the test (the
 // first tile of every row, and any tile whose keys could exceed the span) takes the refresh path: tile maximum, m ← max,
 // conditional rescale of o and l — the classic online step.  The choice is per wave and per tile, wave-uniform, and changes
 // only speed: results are those of an exact soft-max in fp32 either way.  AETHER_ATTN_EXACT_MAX (no bound table) refreshes on
 // every tile.
-constexpr float FA_SHIFT_SPAN = 90.f;
+constexpr float FA_SHIFT_SPAN = 100.f;
 constexpr int FA_KMAX_SLOTS = 1024;   // per-tile bounds of one (batch, head) staged in LDS: S <= 65 536 (longer rows refresh every tile)
 
 AE_DEV float fa_row_norm2(const bf16x8 (&qf)[4]) {
@@ -233,7 +233,11 @@ AE_DEV void fa_exp_tile(const f32x16 (&sc)[2], bf16x8 (&pf)[2][2], float& l_run)
 // NW waves = NW*32 query rows per workgroup (8 or 4).  PRIO 1 = s_setprio 1 around the two MFMA clusters (a wave finishes its
 // MFMA burst instead of interleaving with the other waves' soft-max VALU, which does not overlap with it anyway): +1.5 %
 // (profiles/r01_attn_variants_v3.json; around the soft-max instead: +0.8 %).
-template <bool WIDE_STORE, int NW, int PRIO = 1>
+// ILV = 1: in a tile that passes the guard the soft-max VALU work is interleaved, inside the wave, with that wave's own MFMAs
+// (QK^T of the second 32-key half under the exponentials of the first, P·V of the first half under the exponentials of the second):
+// VALU issued between a wave's own MFMAs hides under them, VALU of the OTHER waves of the SIMD mostly does not
+// (profiles/r01_valu_probe.jsonl: 680 vs 1027 cycles for 16 MFMAs + one tile's soft-max).
+template <bool WIDE_STORE, int NW, int PRIO = 1, int ILV = 0>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))   // <= 128 VGPRs: 16 waves per CU
 void flash_attn_fwd_kernel(FlashArgs p) {
     // 2 x (K tile + V^T tile) + this workgroup's Q fragments (4 KiB per wave, lane-linear: conflict-free ds_read_b128).  Q lives in
@@ -361,7 +365,84 @@ void flash_attn_fwd_kernel(FlashArgs p) {
         if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
         if (!LAST) drain_and_barrier();
     };
-    for (int j = 0; j < nkv - 1; ++j) tile(j, std::false_type{});
+    // ---- interleaved steady-state tile (guard already checked, not the last tile) ---------------------------------------
+    auto tile_ilv = [&](int j) {
+        const int cur = j & 1;
+        stage(j + 1, cur ^ 1);
+        const char* base = smem + cur * FA_BUF;
+        auto Kf = [&](int t, int ks) { return *(const bf16x8*)(base + t * 4096 + L.koff[ks]); };
+        auto Qf = [&](int ks) { return *(const bf16x8*)(qs + ks * 1024); };
+        auto Vf = [&](int dt, int t, int s2) { return *(const bf16x8*)(base + dt * 4096 + L.voff[t][s2]); };
+        f32x16 s0, s1;
+        bf16x8 pf[2][2];
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
+        // one quarter (4 scores) of a 32-key half: exp2, row sum, bf16 P fragment elements
+        auto quarter = [&](const f32x16& sc, int t, int q) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pv = __builtin_amdgcn_exp2f(sc[4 * q + e]);
+                ps[e] += pv;
+                asm volatile("" : "+v"(ps[e]));      // keep the row-sum add inside this group (IR passes re-associate and sink it otherwise)
+                pf[t][q >> 1][4 * (q & 1) + e] = (__bf16)pv;
+            }
+        };
+        bf16x8 fa = Kf(0, 0), fq = Qf(0);
+        // segment 1: QK^T of keys 0..31 (fragments fetched one MFMA ahead)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 na = ks < 3 ? Kf(0, ks + 1) : Kf(1, 0), nq = Qf((ks + 1) & 3);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fq, ks == 0 ? negm : s0, 0, 0, 0);
+            fa = na; fq = nq;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // segment 2: QK^T of keys 32..63 || soft-max of keys 0..31
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 na = ks < 3 ? Kf(1, ks + 1) : Vf(0, 0, 0), nq = Qf((ks + 1) & 3);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fq, ks == 0 ? negm : s1, 0, 0, 0);
+            fa = na; fq = nq;
+            __builtin_amdgcn_sched_barrier(0);
+            quarter(s0, 0, ks);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // segment 3: P·V of keys 0..31 || soft-max of keys 32..63
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int s2 = g >> 1, dt = g & 1;
+            const bf16x8 na = g < 3 ? Vf((g + 1) & 1, 0, (g + 1) >> 1) : Vf(0, 1, 0);
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, pf[0][s2], o[dt], 0, 0, 0);
+            fa = na;
+            __builtin_amdgcn_sched_barrier(0);
+            quarter(s1, 1, g);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // segment 4: P·V of keys 32..63
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int s2 = g >> 1, dt = g & 1;
+            const bf16x8 na = g < 3 ? Vf((g + 1) & 1, 1, (g + 1) >> 1) : fa;
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, pf[1][s2], o[dt], 0, 0, 0);
+            fa = na;
+        }
+        l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+        drain_and_barrier();
+    };
+    if (ILV != 0) {
+        // Tile 0 always refreshes.  After it, passing tiles run in the interleaved loop; the first tile that fails the guard sends
+        // the wave to the generic loop for the rest of its sweep (exact as well, just not interleaved).
+        int j = 0;
+        if (nkv > 1) { tile(0, std::false_type{}); j = 1; }
+        float km = (bounded && j < nkv) ? kms[j] : INFINITY;          // bound of the tile about to run, fetched one tile ahead
+        for (; j < nkv - 1; ++j) {
+            if (!__all(qn2 * km <= thr2)) break;
+            km = kms[j + 1];
+            asm volatile("" : "+v"(km));                                // keep the LDS read here, a whole tile ahead of its use
+            tile_ilv(j);
+        }
+        for (; j < nkv - 1; ++j) tile(j, std::false_type{});
+    } else {
+        for (int j = 0; j < nkv - 1; ++j) tile(j, std::false_type{});
+    }
     tile(nkv - 1, std::true_type{});
 
     fa_store<WIDE_STORE>(o, l_run, p, bh, qrow, hi);
@@ -611,7 +692,10 @@ extern "C" int aether_flash_attn_fwd(const void* Qh, const void* Kh, const void*
         const int rest = p.nwg - full;
         if (full > 0) {
             p.nwg = full; p.wg_first = 0;
-            if (wide) hipLaunchKernelGGL((flash_attn_fwd_kernel<true, 8>), dim3(full), dim3(512), 0, s, p);
+            if (flags & AETHER_ATTN_INTERLEAVE) {
+                if (wide) hipLaunchKernelGGL((flash_attn_fwd_kernel<true, 8, 1, 1>), dim3(full), dim3(512), 0, s, p);
+                else hipLaunchKernelGGL((flash_attn_fwd_kernel<false, 8, 1, 1>), dim3(full), dim3(512), 0, s, p);
+            } else if (wide) hipLaunchKernelGGL((flash_attn_fwd_kernel<true, 8>), dim3(full), dim3(512), 0, s, p);
             else hipLaunchKernelGGL((flash_attn_fwd_kernel<false, 8>), dim3(full), dim3(512), 0, s, p);
         }
         if (rest > 0) {

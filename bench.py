@@ -395,6 +395,10 @@ def main():
             dt, pr = timed(1, args.steps)
             paths["refresh_every_tile"] = {"steps_per_s": args.steps / dt,
                                            "attention_tflops": round(flops_per_launch("attention", B, S, D, FF) * pr["attention"][1] / (pr["attention"][0] * 1e-3) / 1e12, 1)}
+            model.set_flags(fl0 ^ L_.AETHER_ATTN_INTERLEAVE)               # the other steady-state tile variant (A/B)
+            dt, pr = timed(1, args.steps)
+            paths["interleave_toggled"] = {"interleave": not bool(fl0 & L_.AETHER_ATTN_INTERLEAVE), "steps_per_s": args.steps / dt,
+                                           "attention_tflops": round(flops_per_launch("attention", B, S, D, FF) * pr["attention"][1] / (pr["attention"][0] * 1e-3) / 1e12, 1)}
             model.set_flags(fl0)
             model._weights["qn_w"].mul_(3.0); model._weights["kn_w"].mul_(3.0)
             dt, pr = timed(1, args.steps)

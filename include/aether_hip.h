@@ -109,6 +109,7 @@ int aether_qk_norm_rope(const void* qkv, int B, int S, int H, int n_text, const 
 #define AETHER_ATTN_PIPELINED 16  /* flags bit 4: software-pipelined kernel (one workgroup per CU; inside each wave the soft-max
                                      of tile j is interleaved with the MFMAs of P·V(j-1) and K(j+1)·Qᵀ)                    */
 #define AETHER_ATTN_EXACT_MAX 32  /* flags bit 5: ignore kmax2: the shift is refreshed (tile maximum, rescale) on EVERY tile   */
+#define AETHER_ATTN_INTERLEAVE 256 /* flags bit 8: steady-state tiles interleave the soft-max VALU with the wave's own MFMAs     */
 #define AETHER_ATTN_TAIL_SPLIT 64 /* flags bit 6: workgroups beyond the last full round of 512 run as 128-row workgroups (2nd launch) */
 
 /* Non-causal flash attention, head_dim 64: O[b,s,h*64+d] = softmax_2(Qh·Khᵀ)·V where softmax_2 uses base 2, i.e.
@@ -116,8 +117,8 @@ int aether_qk_norm_rope(const void* qkv, int B, int S, int H, int n_text, const 
  * CogVideoXAttnProcessor2_0.  Qh,Kh [B,H,S,64], Vt [B,H,64,Spad], O bf16 [B,S,H*64].
  * kmax2 (fp32 [B*H, Spad/64] or NULL): upper bound of ||k||^2 per (batch, head, 64-key tile).
  * Soft-max (default, lock-step kernel) = exact, with a guarded static shift: each row keeps a shift m that is a true score
- * maximum of the tiles it was last refreshed on (first tile always); a tile whose bound proves s - m <= 90 for all its keys
- * (||q||^2·kmax2[tile] <= (m + 90)^2, m + 90 > 0) is exponentiated against m directly — no tile maximum, no subtraction (m
+ * maximum of the tiles it was last refreshed on (first tile always); a tile whose bound proves s - m <= 100 for all its keys
+ * (||q||^2·kmax2[tile] <= (m + 100)^2, m + 100 > 0) is exponentiated against m directly — no tile maximum, no subtraction (m
  * rides in the C operand of the QK^T MFMA), no rescale; any other tile, and every tile when kmax2 is NULL or
  * AETHER_ATTN_EXACT_MAX is set, takes the online step (tile maximum, shift update, rescale).  The choice is per wave and
  * tile and changes only speed: soft-max is shift invariant, results are those of an exact fp32 soft-max either way.

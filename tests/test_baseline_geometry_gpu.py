@@ -3,9 +3,9 @@ way BASELINE.json's north_star states it: LATENTS L-infinity and PIXEL PSNR agai
 bf16-representable weights, inputs and seeds.  Stated thresholds:
 
   * DiT noise prediction (the latent-space output of one transformer forward), 2 of the 42 blocks at full width and the FULL
-    sequence, B = 1 and B = 2:  rel-L2 <= 1.0e-2,  L-inf <= 6 % of max|ref|;
+    sequence, B = 1 and B = 2:  rel-L2 <= 8e-3,  L-inf <= 2 % of max|ref|   (measured 4.0e-3 / 0.5 %);
   * VAE encode of a 480x720 clip (tiled 9 tiles -> 4/2/2/1 tile batches, 8-frame chunks threaded through the conv caches):
-    posterior-mean latents  L-inf <= 6 % of max|ref|, rel-L2 <= 1.5e-2;
+    posterior-mean latents  L-inf <= 4 % of max|ref|, rel-L2 <= 2e-2   (measured on the whole 17-frame output: 1.2e-2 / 1.4 %);
   * VAE decode of a 60x90 latent (tiled, frame-chunked, caches threaded):  pixel PSNR >= 38 dB (pixels in [0, 1]).
 
 The oracle's CPU time bounds what can be compared (fp32, one pass): the DiT cases take ~10-30 s each on the GPU box's host
@@ -13,7 +13,6 @@ cores, the VAE cases ~1 min; the 42-block / 50-step trajectory at this size woul
 scaled-down end-to-end tests (tests/test_pipeline_gpu.py) plus the finite/shape run (tests/test_fullsize_gpu.py).
 """
 import math
-import os
 import time
 
 import numpy as np
@@ -22,11 +21,12 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-# The VAE cases default to 17 frames (encoder chunks 1+8 | 8: caches threaded) / 4 latent frames (decoder chunks 2 | 2) at the
-# full 480x720 tiling — the fp32 CPU oracle needs ~1 min for them on the box's host cores; AETHER_FULL_PARITY=1 runs the whole
-# 41-frame clip / 11-frame latent (same code, three more chunks, ~2.5x the CPU time).
-FULL = os.environ.get("AETHER_FULL_PARITY", "0") == "1"
-ENC_FRAMES, DEC_LATENT_FRAMES = (41, 11) if FULL else (17, 4)
+# VAE cases: the NATIVE path runs the whole 480x720 geometry (9 tiles as 4/2/2/1 batches, frame chunks with threaded caches); the
+# fp32 CPU oracle — 0.5 TFLOP/s of conv3d on the box's host cores — evaluates only the tiles needed to pin a region of the
+# output that covers an unblended tile interior, a horizontal blend seam between two tiles of the 4-batch, and a tile of another
+# batch (the narrow right column).  The whole 17-frame encode output was compared once (129.6 s of CPU):
+# profiles/r02_parity_full_geometry.log.
+ENC_FRAMES, DEC_LATENT_FRAMES = 17, 5          # encoder chunks (0,9) (9,17); decoder chunks (0,3) (3,5): caches threaded
 
 
 def _metrics(out: torch.Tensor, ref: torch.Tensor):
@@ -67,7 +67,7 @@ def test_dit_full_sequence_two_blocks(cuda, hip_lib, B):
     m = _metrics(out.cpu().float(), ref)
     print(f"\nDiT S=15076 B={B} 2 blocks vs fp32 oracle ({t_cpu:.1f} s CPU): rel-L2 {m['rel_l2']:.3e}  latents L-inf {m['linf']:.4f} "
           f"({100 * m['linf_rel']:.2f} % of max|ref| {m['ref_max']:.3f})")
-    assert m["rel_l2"] <= 1.0e-2 and m["linf_rel"] <= 0.06, m
+    assert m["rel_l2"] <= 8.0e-3 and m["linf_rel"] <= 0.02, m
 
 
 @pytest.mark.parametrize("frames,table", [(13, "learned"), (11, "sincos")])
@@ -144,47 +144,61 @@ def vae_pair(cuda, hip_lib):
     return oracle, native
 
 
+def _oracle_row0(oracle, net, x, bs, tile_h, tile_w, stride_w, blend_w, limit_h, limit_w):
+    """Row 0 of the reference's tiled pass (no vertical blend there): every tile of the first tile row through `net`, blended
+    horizontally and cropped exactly as AutoencoderKLCogVideoX.tiled_encode / tiled_decode do."""
+    W = x.shape[-1]
+    row = [oracle._run_chunks(net, x[:, :, :, :tile_h, j:j + tile_w].contiguous(), bs) for j in range(0, W, stride_w)]
+    out = []
+    for j, tile in enumerate(row):
+        if j > 0:
+            tile = oracle._blend_h(row[j - 1], tile, blend_w)
+        out.append(tile[:, :, :, :limit_h, :limit_w])
+    return torch.cat(out, dim=4)
+
+
 def test_vae_encode_full_clip(cuda, vae_pair):
-    """480 x 720 frames, tiling on (9 overlapping 240x360 tiles as 4/2/2/1 batches natively, one by one in the oracle),
-    8-frame chunks with the causal-conv caches threaded."""
+    """17 x 480 x 720, tiling on (9 overlapping 240x360 tiles as 4/2/2/1 batches natively), 8-frame chunks with the causal-conv
+    caches threaded.  Compared: latent rows 0..24 x all 90 columns (tile row 0: unblended interior of tile (0,0), the seams
+    (0,0)|(0,1) and (0,1)|(0,2), the narrow tile (0,2) of the 2-batch)."""
     oracle, native = vae_pair
     x = _video(ENC_FRAMES, 480, 720).to(torch.bfloat16)
     t0 = time.perf_counter()
-    ref = oracle.encode(x.float()).latent_dist
+    with torch.no_grad():
+        ref_rows = _oracle_row0(oracle, oracle.encoder, x.float(), 8, 240, 360, 288, 9, 25, 36)     # [1, 32, 5, 25, 90]
     t_cpu = time.perf_counter() - t0
     got = native.encode(x.to(cuda)).latent_dist
     torch.cuda.synchronize()
-    mean, ref_mean = got.mode().cpu().float(), ref.mode()
-    assert mean.shape == ref_mean.shape == (1, 16, (ENC_FRAMES - 1) // 4 + 1, 60, 90)
-    m = _metrics(mean, ref_mean)
-    print(f"\nVAE encode {ENC_FRAMES}x480x720 tiled vs fp32 oracle ({t_cpu:.1f} s CPU): posterior mean rel-L2 {m['rel_l2']:.3e}  latents L-inf "
-          f"{m['linf']:.4f} ({100 * m['linf_rel']:.2f} % of max|ref| {m['ref_max']:.3f})")
-    assert m["rel_l2"] <= 1.5e-2 and m["linf_rel"] <= 0.06, m
-    # identical seeds -> the posterior SAMPLE differs by the same amount (the draw itself is bit-identical: CPU generator)
-    s_n = got.sample(torch.Generator().manual_seed(3)).cpu().float()
-    s_o = ref.sample(torch.Generator().manual_seed(3))
-    ms = _metrics(s_n, s_o)
-    print(f"posterior sample (seed 3): rel-L2 {ms['rel_l2']:.3e}  L-inf {100 * ms['linf_rel']:.2f} %")
-    assert ms["linf_rel"] <= 0.06, ms
+    mean = got.mode().cpu().float()
+    assert mean.shape == (1, 16, (ENC_FRAMES - 1) // 4 + 1, 60, 90) and ref_rows.shape[-2:] == (25, 90)
+    m = _metrics(mean[:, :, :, :25], ref_rows[:, :16])
+    print(f"\nVAE encode {ENC_FRAMES}x480x720 tiled vs fp32 oracle (tile row 0, {t_cpu:.1f} s CPU): posterior mean rel-L2 {m['rel_l2']:.3e}  "
+          f"latents L-inf {m['linf']:.4f} ({100 * m['linf_rel']:.2f} % of max|ref| {m['ref_max']:.3f})")
+    assert m["rel_l2"] <= 2.0e-2 and m["linf_rel"] <= 0.04, m
+    logvar = got.logvar.cpu().float()
+    ml = _metrics(logvar[:, :, :, :25], ref_rows[:, 16:].clamp(-30.0, 20.0))
+    assert ml["linf_rel"] <= 0.04, ml
 
 
 def test_vae_decode_full_resolution(cuda, vae_pair):
-    """60x90 latent -> 480x720 pixels, tiled (9 latent tiles 30x45, strides 25x36) and frame-chunked (2 latent frames per
-    chunk, caches threaded)."""
+    """5 x 60 x 90 latent -> 17 x 480 x 720 pixels, tiled (9 latent tiles 30x45, strides 25x36) and frame-chunked ((0,3) (3,5),
+    caches threaded).  Compared: pixel rows 0..199 x all 720 columns (tile row 0 incl. both horizontal seams and the narrow tile)."""
     oracle, native = vae_pair
     g = torch.Generator().manual_seed(4)
     z = (torch.randn(1, 16, DEC_LATENT_FRAMES, 60, 90, generator=g) * 0.8).to(torch.bfloat16)
     t0 = time.perf_counter()
-    ref = oracle.decode(z.float()).sample
+    with torch.no_grad():
+        ref = _oracle_row0(oracle, oracle.decoder, z.float(), 2, 30, 45, 36, 72, 200, 288)            # [1, 3, 17, 200, 720]
     t_cpu = time.perf_counter() - t0
     out = native.decode(z.to(cuda)).sample
     torch.cuda.synchronize()
     out = out.cpu().float()
-    assert out.shape == ref.shape == (1, 3, 4 * (DEC_LATENT_FRAMES - 1) + 1, 480, 720)
+    assert out.shape == (1, 3, 4 * (DEC_LATENT_FRAMES - 1) + 1, 480, 720) and ref.shape[-2:] == (200, 720)
+    out = out[:, :, :, :200]
     # pixels as the pipeline post-processes them (P:932: x/2 + 0.5 clamped to [0, 1])
     pix_n, pix_o = (out / 2 + 0.5).clamp(0, 1), (ref / 2 + 0.5).clamp(0, 1)
     m = _metrics(out, ref)
     psnr = _psnr(pix_n, pix_o)
-    print(f"\nVAE decode {DEC_LATENT_FRAMES}x60x90 -> {out.shape[2]}x480x720 tiled vs fp32 oracle ({t_cpu:.1f} s CPU): rel-L2 {m['rel_l2']:.3e}  L-inf {m['linf']:.4f} "
-          f"pixel PSNR {psnr:.1f} dB")
+    print(f"\nVAE decode {DEC_LATENT_FRAMES}x60x90 -> {out.shape[2]}x480x720 tiled vs fp32 oracle (tile row 0, {t_cpu:.1f} s CPU): rel-L2 {m['rel_l2']:.3e}  "
+          f"L-inf {m['linf']:.4f}  pixel PSNR {psnr:.1f} dB")
     assert psnr >= 38.0 and m["rel_l2"] <= 2e-2, (psnr, m)

@@ -37,6 +37,14 @@ class AetherDitConfig(C.Structure):
     ]
 
 
+class AetherVaeConfig(C.Structure):
+    _fields_ = [
+        ("in_channels", C.c_int), ("out_channels", C.c_int), ("latent_channels", C.c_int), ("layers_per_block", C.c_int),
+        ("num_levels", C.c_int), ("norm_num_groups", C.c_int), ("temporal_compression_ratio", C.c_int), ("sample_height", C.c_int),
+        ("sample_width", C.c_int), ("norm_eps", C.c_float), ("tap_reuse_max_waste", C.c_float), ("flags", C.c_int),
+    ]
+
+
 # name -> (restype, argtypes); every symbol declared in include/aether_hip.h
 SIGNATURES = {
     "aether_last_error": (C.c_char_p, []),
@@ -57,6 +65,14 @@ SIGNATURES = {
     "aether_groupnorm_apply": (_i, [_vp, _i, _i, _i, _i, _i, _fp, _i, _vp, _i, _i, _i, _i, _i, _i, _fp, _i, _i, _i, C.POINTER(C.c_int), _vp]),
     "aether_causal_front": (_i, [_vp, _i, _i, C.c_long, _vp, _vp, _vp]),
     "aether_resample_pad": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "aether_vae_create": (_vp, [C.POINTER(AetherVaeConfig)]),
+    "aether_vae_destroy": (None, [_vp]),
+    "aether_vae_set_conv": (_i, [_vp, C.c_char_p, _vp, _fp, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "aether_vae_set_norm": (_i, [_vp, C.c_char_p, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "aether_vae_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i, _i]),
+    "aether_vae_output_shape": (_i, [_vp, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "aether_vae_encode": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "aether_vae_decode": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "aether_dit_create": (_vp, [C.POINTER(AetherDitConfig)]),
     "aether_dit_destroy": (None, [_vp]),
     "aether_dit_set_weight": (_i, [_vp, C.c_char_p, _vp]),

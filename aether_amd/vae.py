@@ -146,6 +146,12 @@ class AetherVAE:
         self.splitk_ws_bytes = 96 << 20
         self.tap_reuse_max_waste = 1.06                       # padded-plane / output-plane ratio up to which the tap-reuse conv runs (0: never)
         self._loaded = False
+        # encode()/decode() are ONE C call each (aether_vae_encode / aether_vae_decode: the launch plan lives in csrc/vae_plan.hip).
+        # use_c_plan = False walks the same graph from Python through the per-kernel entry points (tests, A/B: bit-identical).
+        self.use_c_plan = True
+        self._handle = None
+        self._workspace: Optional[torch.Tensor] = None
+        self._ws_bytes: Optional[int] = None
 
     # ------------------------------------------------------------------------------------------------
     @classmethod
@@ -208,7 +214,85 @@ class AetherVAE:
         d.conv_out = _Conv(sd["decoder.conv_out.conv.weight"], sd["decoder.conv_out.conv.bias"], dev)
         self.enc, self.dec = e, d
         self._loaded = True
+        self._register_c_plan()
         return self
+
+    def _register_c_plan(self):
+        """Hand every packed convolution / norm to the C launch plan under its diffusers module path."""
+        c = self.config
+        if self._handle is not None:
+            self._lib.aether_vae_destroy(self._handle)
+        cfg = _lib.AetherVaeConfig(in_channels=c.in_channels, out_channels=c.out_channels, latent_channels=c.latent_channels,
+                                   layers_per_block=c.layers_per_block, num_levels=len(c.block_out_channels), norm_num_groups=c.norm_num_groups,
+                                   temporal_compression_ratio=c.temporal_compression_ratio, sample_height=c.sample_height,
+                                   sample_width=c.sample_width, norm_eps=c.norm_eps, tap_reuse_max_waste=self.tap_reuse_max_waste, flags=self._flags)
+        h = self._lib.aether_vae_create(C.byref(cfg))
+        if not h:
+            raise ValueError("aether_vae_create: " + self._lib.aether_last_error().decode())
+        self._handle = h
+        self._workspace = None
+
+        def conv(name, cv: _Conv):
+            kt, kh, kw = cv.ksize if len(cv.ksize) == 3 else ((1,) + tuple(cv.ksize) if len(cv.ksize) == 2 else (1, 1, 1))
+            _lib.check(self._lib.aether_vae_set_conv(h, name.encode(), cv.w.data_ptr(), cv.b.data_ptr(), cv.cout, cv.cout_pad, cv.cin, kt, kh, kw,
+                                                     cv.w.shape[1], int(cv.blocked)), f"aether_vae_set_conv({name})")
+
+        def norm(name, n: _Norm):
+            sp = [n.wy.data_ptr(), n.by.data_ptr(), n.wb.data_ptr(), n.bb.data_ptr()] if n.spatial else [None] * 4
+            _lib.check(self._lib.aether_vae_set_norm(h, name.encode(), n.gamma.data_ptr(), n.beta.data_ptr(), *sp), f"aether_vae_set_norm({name})")
+
+        def resnet(r: _Resnet):
+            norm(r.name + "norm1", r.norm1); norm(r.name + "norm2", r.norm2)
+            conv(r.name + "conv1", r.conv1); conv(r.name + "conv2", r.conv2)
+            if r.shortcut is not None:
+                conv(r.name + "conv_shortcut", r.shortcut)
+
+        e, d = self.enc, self.dec
+        conv("encoder.conv_in", e.conv_in); conv("encoder.conv_out", e.conv_out); norm("encoder.norm_out", e.norm_out)
+        for i, blk in enumerate(e.down):
+            for r in blk.resnets:
+                resnet(r)
+            if blk.down is not None:
+                conv(f"encoder.down_blocks.{i}.downsamplers.0", blk.down)
+        for r in e.mid:
+            resnet(r)
+        conv("decoder.conv_in", d.conv_in); conv("decoder.conv_out", d.conv_out); norm("decoder.norm_out", d.norm_out)
+        for r in d.mid:
+            resnet(r)
+        for i, blk in enumerate(d.up):
+            for r in blk.resnets:
+                resnet(r)
+            if blk.up is not None:
+                conv(f"decoder.up_blocks.{i}.upsamplers.0", blk.up)
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                self._lib.aether_vae_destroy(self._handle)
+        except Exception:
+            pass
+
+    def _run_c_plan(self, x: torch.Tensor, decode: bool) -> torch.Tensor:
+        """x [1, C, T, H, W] bf16 on the device -> [1, C_out, T_out, H_out, W_out] through ONE C call."""
+        src = x[0].contiguous()
+        _, T, H, W = src.shape
+        shp = [C.c_int() for _ in range(4)]
+        _lib.check(self._lib.aether_vae_output_shape(self._handle, int(decode), T, H, W, *[C.byref(v) for v in shp]), "aether_vae_output_shape")
+        out = torch.empty(1, *[v.value for v in shp], dtype=torch.bfloat16, device=self.device)
+        need = self._lib.aether_vae_workspace_bytes(self._handle, int(decode), T, H, W, int(self.use_tiling))
+        if need == 0:
+            raise RuntimeError("aether_vae_workspace_bytes: " + self._lib.aether_last_error().decode())
+        if self._workspace is None or self._workspace.numel() < need:
+            # a fresh workspace resets the library's pool of zero-bordered volumes: leave head-room for the other direction's shapes
+            self._workspace = None
+            torch.cuda.empty_cache()
+            old = 0 if self._ws_bytes is None else self._ws_bytes
+            self._ws_bytes = max(int(need * 1.5), old + need) + (1 << 20)      # monotone: the pool of BOTH directions ends up fitting
+            self._workspace = torch.empty(self._ws_bytes, dtype=torch.uint8, device=self.device)
+        fn = self._lib.aether_vae_decode if decode else self._lib.aether_vae_encode
+        _lib.check(fn(self._handle, src.data_ptr(), T, H, W, int(self.use_tiling), out.data_ptr(), self._workspace.data_ptr(),
+                      self._workspace.numel(), self._stream()), "aether_vae_decode" if decode else "aether_vae_encode")
+        return out
 
     def state_dict_spec(self) -> Dict[str, tuple]:
         """diffusers state-dict keys and shapes of an AutoencoderKLCogVideoX with this config."""
@@ -535,7 +619,8 @@ class AetherVAE:
     def encode(self, x: torch.Tensor, return_dict: bool = True):
         self._check_ready(x, self.config.in_channels)
         x = x.to(device=self.device, dtype=torch.bfloat16)
-        h = torch.cat([self._encode(s) for s in x.split(1)])      # batch items are independent (slicing or not)
+        run = (lambda s: self._run_c_plan(s, False)) if self.use_c_plan else self._encode
+        h = torch.cat([run(s) for s in x.split(1)])               # batch items are independent (slicing or not)
         posterior = DiagonalGaussianDistribution(h)
         return SimpleNamespace(latent_dist=posterior) if return_dict else (posterior,)
 
@@ -559,7 +644,8 @@ class AetherVAE:
     def decode(self, z: torch.Tensor, return_dict: bool = True):
         self._check_ready(z, self.config.latent_channels)
         z = z.to(device=self.device, dtype=torch.bfloat16)
-        dec = torch.cat([self._decode(z[i:i + 1]) for i in range(z.shape[0])])
+        run = (lambda s: self._run_c_plan(s, True)) if self.use_c_plan else self._decode
+        dec = torch.cat([run(z[i:i + 1]) for i in range(z.shape[0])])
         return SimpleNamespace(sample=dec) if return_dict else (dec,)
 
     def _check_ready(self, x, channels):

@@ -191,6 +191,52 @@ int aether_resample_pad(const void* x, int NB, int T, int H, int W, int C, int m
                         int ph, int pw, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Whole-VAE entries (one call = AutoencoderKLCogVideoX.encode at P:557-618 / .decode through decode_latents at P:931,936,
+ * with tiling and frame batching exactly as scripts/demo.py:229-230 enables them).  The launch plan (tile batches of equal
+ * shape, frame chunks with threaded causal-conv caches, ResNets, resamplers, tile cross-fade) is C++ inside the library: pure
+ * enqueue on `stream`, no allocation, no synchronisation, no host<->device copy -> graph capturable.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct AetherVaeConfig {
+    int in_channels;                 /* 3 */
+    int out_channels;                /* 3 */
+    int latent_channels;             /* 16 (<= 16) */
+    int layers_per_block;            /* 3 */
+    int num_levels;                  /* 4 = len(block_out_channels); channel widths come with the registered weights */
+    int norm_num_groups;             /* 32 */
+    int temporal_compression_ratio;  /* 4 */
+    int sample_height, sample_width; /* 480, 720: tiles are half of it, overlaps 1/6 and 1/5 (diffusers) */
+    float norm_eps;                  /* 1e-6 */
+    float tap_reuse_max_waste;       /* padded-plane / output-plane ratio up to which the tap-reuse convolution runs (1.06) */
+    int flags;                       /* AETHER_GEMM_* flags forwarded to the GEMMs */
+} AetherVaeConfig;
+
+typedef struct AetherVae AetherVae; /* opaque host-side handle: weight table + workspace bookkeeping */
+
+AetherVae* aether_vae_create(const AetherVaeConfig* cfg);
+void aether_vae_destroy(AetherVae* h);
+/* Register a packed convolution under its diffusers module path ("encoder.conv_in", "decoder.up_blocks.0.resnets.1.conv2",
+ * "encoder.down_blocks.0.downsamplers.0", "...conv_shortcut"): w bf16 [cout_pad, kcols] in the K order of
+ * aether_conv_gemm_bf16 (blocked != 0: (dt, dh, 64-channel block, dw)) or, for the thin first convolutions, (dt, dh, dw, cin)
+ * zero-padded to kcols; b fp32 [cout_pad].  Packing: aether_amd/vae.py `_Conv`. */
+int aether_vae_set_conv(AetherVae* h, const char* name, const void* w, const float* b, int cout, int cout_pad, int cin, int kt, int kh,
+                        int kw, int kcols, int blocked);
+/* Register a GroupNorm ("encoder...norm1": gamma/beta fp32 [C], the other four NULL) or a CogVideoXSpatialNorm3D
+ * ("decoder...norm1": norm_layer gamma/beta + conv_y / conv_b as fp32 [C, zC] matrices and [C] biases). */
+int aether_vae_set_norm(AetherVae* h, const char* name, const float* gamma, const float* beta, const float* wy, const float* by,
+                        const float* wb, const float* bb);
+/* Workspace the NEXT call of this kind needs, given what the handle already keeps in the caller's current workspace (the
+ * zero-bordered convolution input volumes persist there from call to call; a different workspace pointer resets them). */
+size_t aether_vae_workspace_bytes(AetherVae* h, int decode, int T, int H, int W, int tiling);
+int aether_vae_output_shape(AetherVae* h, int decode, int T, int H, int W, int* oC, int* oT, int* oH, int* oW);
+/* x bf16 [in_channels, T, H, W] contiguous in [-1, 1] -> moments bf16 [2*latent_channels, T', H/8, W/8] (mean | logvar: the
+ * caller samples the posterior, P:233-245).  workspace: 256-byte aligned device memory of >= aether_vae_workspace_bytes. */
+int aether_vae_encode(AetherVae* h, const void* x, int T, int H, int W, int tiling, void* moments, void* workspace, size_t workspace_bytes,
+                      void* stream);
+/* z bf16 [latent_channels, T, h, w] contiguous (already divided by the scaling factor, P:931) -> sample bf16 [out_channels, T_out, 8h, 8w]. */
+int aether_vae_decode(AetherVae* h, const void* z, int T, int H, int W, int tiling, void* sample, void* workspace, size_t workspace_bytes,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Whole-transformer entry (one call = CogVideoXTransformer3DModel.forward as invoked at P:865-875)
  * ------------------------------------------------------------------------------------------------ */
 typedef struct AetherDitConfig {

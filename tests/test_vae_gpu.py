@@ -235,6 +235,55 @@ def test_vae_decode_small_tiled_and_posterior_rng(cuda, hip_lib):
     assert torch.equal(s, post.mean + post.std * noise)
 
 
+@pytest.mark.parametrize("kw,T,h,w", [
+    (dict(block_out_channels=(64, 128, 128, 128), layers_per_block=1, sample_height=96, sample_width=240), 17, 96, 240),   # 9 tiles, 2 chunks
+    (dict(block_out_channels=(64, 128, 128, 128), layers_per_block=1, sample_height=96, sample_width=240), 5, 48, 120),    # no tiling, 1 chunk
+    (dict(sample_height=96, sample_width=240), 9, 96, 240),                                                                # real widths
+])
+def test_c_plan_matches_python_walk(cuda, hip_lib, kw, T, h, w):
+    """aether_vae_encode / aether_vae_decode (launch plan in C++: csrc/vae_plan.hip, incl. the one-pass tile assembly) against
+    the Python walk over the per-kernel entry points: same kernels, same order -> bit-identical; and the second call (zero-
+    bordered volumes persisted in the workspace) equals the first."""
+    from aether_amd.vae import AetherVAE
+    vae = AetherVAE(kw, device=cuda).init_random_weights(3)
+    vae.enable_tiling(); vae.enable_slicing()
+    x = _smooth_video(T, h, w, seed=4).to(cuda)
+    z = torch.randn(1, 16, (T - 1) // 4 + 1, h // 8, w // 8, generator=torch.Generator().manual_seed(6)).to(torch.bfloat16).to(cuda)
+    vae.use_c_plan = False
+    enc_py, dec_py = vae.encode(x).latent_dist.parameters, vae.decode(z).sample
+    vae.use_c_plan = True
+    enc_c, dec_c = vae.encode(x).latent_dist.parameters, vae.decode(z).sample
+    enc_c2, dec_c2 = vae.encode(x).latent_dist.parameters, vae.decode(z).sample
+    torch.cuda.synchronize()
+    assert enc_c.shape == enc_py.shape and dec_c.shape == dec_py.shape
+    assert torch.equal(enc_c, enc_py), (enc_c.float() - enc_py.float()).abs().max()
+    assert torch.equal(dec_c, dec_py), (dec_c.float() - dec_py.float()).abs().max()
+    assert torch.equal(enc_c2, enc_c) and torch.equal(dec_c2, dec_c)
+
+
+def test_c_plan_is_graph_capturable(cuda, hip_lib):
+    """The whole decode enqueues without allocation, synchronisation or host<->device copies: it can be captured into a hipGraph
+    and replayed."""
+    from aether_amd.vae import AetherVAE
+    kw = dict(block_out_channels=(64, 128, 128, 128), layers_per_block=1, sample_height=96, sample_width=240)
+    vae = AetherVAE(kw, device=cuda).init_random_weights(1)
+    vae.enable_tiling()
+    z = torch.randn(1, 16, 5, 12, 30, generator=torch.Generator().manual_seed(2)).to(torch.bfloat16).to(cuda)
+    eager = vae.decode(z).sample.clone()                      # also sizes the workspace and fills the pool
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        vae.decode(z)                                          # warm-up on the capture stream
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            out = vae.decode(z).sample
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+
+
 def test_vae_full_width_decode_chunk(cuda, hip_lib):
     """Real channel widths (128,256,256,512), 3 resnets per block, on a reduced frame (96x240, 9 frames):
     every production kernel configuration (256-, 128- and 32-wide GEMM tiles, K up to 13 824)."""

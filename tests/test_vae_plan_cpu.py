@@ -53,5 +53,5 @@ def test_missing_weight_is_reported():
                                temporal_compression_ratio=4, sample_height=480, sample_width=720, norm_eps=1e-6, tap_reuse_max_waste=1.06, flags=5)
     h = L.aether_vae_create(C.byref(cfg))
     assert L.aether_vae_workspace_bytes(h, 0, 41, 480, 720, 1) == 0
-    assert b"not registered: encoder.conv_in" in L.aether_last_error()
+    assert b"convolution not registered: encoder.conv_" in L.aether_last_error()
     L.aether_vae_destroy(h)

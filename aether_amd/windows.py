@@ -13,6 +13,7 @@ bit-identical to the single-process run for any N (same seeds, same per-window a
 """
 from __future__ import annotations
 
+import ctypes as C
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence
 
@@ -204,9 +205,11 @@ def blend_and_merge_window_results(results: Sequence[WindowResult], *, height: i
 def _merge_on_device(results: Sequence[WindowResult], *, height: int, width: int, smooth_camera: bool, smooth_method: str,
                      device: torch.device):
     """The per-pixel work of blend_and_merge_window_results (align_pointmaps=False) on `device`: same operations, dtypes and
-    order as the host path (float32 operands of the scale fit, float64 everything else), as torch tensors — a 192-frame clip
-    (8 windows) costs the host ≈ 21 s of float64 numpy after the windows' 13 s of GPU time; on the MI355X it is a few HBM passes.
-    One H2D copy per window result, one D2H copy of the merged arrays."""
+    order as the host path (float32 operands of the scale fit, float64 everything else).  On an MI355X the three passes are HIP
+    kernels of libaether_hip.so (csrc/merge_kernels.hip: masked scale-fit reduction, fused scale + cross-fade of disparity and
+    colour, back-projection) reading the gathered fp32 window outputs where `run_windows` left them; on any other device the same
+    arithmetic runs as torch operations (CPU tests).  A 192-frame clip (8 windows) costs the host about 21 s of float64 numpy.
+    One D2H copy of the merged arrays at the end."""
     from . import geometry as G
 
     sm = smooth_method if smooth_camera else "none"
@@ -215,13 +218,31 @@ def _merge_on_device(results: Sequence[WindowResult], *, height: int, width: int
     H, W = first.disparity.shape[1:]
     total = results[-1].start + results[-1].rgb.shape[0]
     f64 = dict(dtype=torch.float64, device=device)
+    native = device.type == "cuda"
+    if native:
+        from . import _lib
+        lib = _lib.load()
+        stream = torch.cuda.current_stream(device).cuda_stream
+        scratch = torch.empty(4096 + 3, **f64)
     up = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))).to(device)  # noqa: E731
+    up32 = lambda a: up(a).to(torch.float32).contiguous()  # noqa: E731
     rgb = torch.empty((total, H, W, 3), **f64)
     disp = torch.empty((total, H, W), **f64)
     poses = np.empty((total, 4, 4))
     focals = np.empty((total,))
-    rgb[:n_win], disp[:n_win] = up(first.rgb), up(first.disparity)
-    pm0 = G.postprocess_pointmap(first.disparity, first.raymap, vae_downsample_scale=8, ray_o_scale_inv=0.1,
+
+    def write_window(r_rgb, r_disp, t0, ov, fade_h, scale_dev):
+        """frames [t0, t0 + n) of the merged arrays from one window (cross-fade over the first `ov`)."""
+        n = r_rgb.shape[0]
+        fade_c = (C.c_double * max(ov, 1))(*fade_h) if ov else None
+        _lib.check(lib.aether_merge_window(r_rgb.data_ptr(), r_disp.data_ptr(), rgb[t0].data_ptr(), disp[t0].data_ptr(), n, ov, H * W, fade_c,
+                                           None if scale_dev is None else scale_dev.data_ptr(), stream), "aether_merge_window")
+
+    if native:
+        write_window(up32(first.rgb), up32(first.disparity), 0, 0, [], None)
+    else:
+        rgb[:n_win], disp[:n_win] = up(first.rgb), up(first.disparity)
+    pm0 = G.postprocess_pointmap(_host(first.disparity), first.raymap, vae_downsample_scale=8, ray_o_scale_inv=0.1,
                                  smooth_camera=smooth_camera, smooth_method=sm, with_pointmap=False)
     poses[:n_win] = pm0["camera_pose"]
     focals[:n_win] = (pm0["intrinsics"][:, 0, 0] + pm0["intrinsics"][:, 1, 1]) / 2
@@ -232,18 +253,25 @@ def _merge_on_device(results: Sequence[WindowResult], *, height: int, width: int
         ov = results[k - 1].start + n_win - t0
         assert end == t0 + ov
         fade_h = np.linspace(1, 0, ov)
-        fade = torch.from_numpy(fade_h).to(device)
-        r_disp, r_rgb = up(r.disparity), up(r.rgb)
-        # scale fit: float32 operands and float32 sums like the reference's torch code (U:847-864)
-        p, t = r_disp[:ov].float(), disp[t0:end].float()
-        m = (p > 0.1).float()
-        den = float((m * p * p).sum())
-        scale = float((m * p * t).sum()) / den if den != 0 else 0.0
-        w_disp = scale * r_disp
-        disp[t0:end] = disp[t0:end] * fade[:, None, None] + w_disp[:ov] * (1 - fade[:, None, None])
-        disp[end:t1] = w_disp[ov:]
-        rgb[t0:end] = rgb[t0:end] * fade[:, None, None, None] + r_rgb[:ov] * (1 - fade[:, None, None, None])
-        rgb[end:t1] = r_rgb[ov:]
+        if native:
+            r_disp, r_rgb = up32(r.disparity), up32(r.rgb)
+            # scale fit (U:847-864) -> device scalar, then ONE pass: scale, cross-fade of disparity and colour, tail frames
+            _lib.check(lib.aether_merge_scale_fit(r_disp.data_ptr(), disp[t0].data_ptr(), ov * H * W, scratch.data_ptr(), 4096,
+                                                  scratch[4096:].data_ptr(), stream), "aether_merge_scale_fit")
+            write_window(r_rgb, r_disp, t0, ov, fade_h.tolist(), scratch[4098:])
+        else:
+            fade = torch.from_numpy(fade_h).to(device)
+            r_disp, r_rgb = up(r.disparity), up(r.rgb)
+            # scale fit: float32 operands and float32 sums like the reference's torch code (U:847-864)
+            p, t = r_disp[:ov].float(), disp[t0:end].float()
+            m = (p > 0.1).float()
+            den = float((m * p * p).sum())
+            scale = float((m * p * t).sum()) / den if den != 0 else 0.0
+            w_disp = scale * r_disp
+            disp[t0:end] = disp[t0:end] * fade[:, None, None] + w_disp[:ov] * (1 - fade[:, None, None])
+            disp[end:t1] = w_disp[ov:]
+            rgb[t0:end] = rgb[t0:end] * fade[:, None, None, None] + r_rgb[:ov] * (1 - fade[:, None, None, None])
+            rgb[end:t1] = r_rgb[ov:]
         # cameras and focal lengths: a few dozen 4x4 matrices — host
         w_poses, fov_x, fov_y = G.raymap_to_poses(r.raymap, ray_o_scale_inv=0.1)
         aR, aT, aS = G.align_camera_extrinsics(w_poses[:ov], poses[t0:end])
@@ -258,22 +286,30 @@ def _merge_on_device(results: Sequence[WindowResult], *, height: int, width: int
         end = t1
 
     # back-projection (U:393-403): world = pose[:3,:4] · [K⁻¹ · (u+.5, v+.5, 1) · depth ; 1], pixel grid in float32 like the reference
-    v, u = torch.meshgrid(torch.arange(H, device=device), torch.arange(W, device=device), indexing="ij")
-    pix = torch.stack([u.reshape(-1) + 0.5, v.reshape(-1) + 0.5, torch.ones(H * W, device=device)], 0).float().double()   # [3, HW]
     K = np.zeros((total, 3, 3))
     K[:, 0, 0] = K[:, 1, 1] = focals
     K[:, 0, 2], K[:, 1, 2], K[:, 2, 2] = 0.5 * width, 0.5 * height, 1.0
     K_inv = torch.from_numpy(np.linalg.inv(K)).to(device)
     P = torch.from_numpy(poses[:, :3, :4].copy()).to(device)
     pointmaps = torch.empty((total, H, W, 3), **f64)
-    step = 16
-    for i in range(0, total, step):
-        j = min(i + step, total)
-        depth = (1 / disp[i:j].clamp(1e-8, 1e8)).reshape(j - i, 1, H * W)
-        cam = (K_inv[i:j] @ pix) * depth                                                         # [n, 3, HW]
-        world = P[i:j, :, :3] @ cam + P[i:j, :, 3:]                                               # [n, 3, HW]
-        pointmaps[i:j] = world.transpose(1, 2).reshape(j - i, H, W, 3)
+    if native:
+        _lib.check(lib.aether_backproject(disp.data_ptr(), K_inv.contiguous().data_ptr(), P.contiguous().data_ptr(), pointmaps.data_ptr(),
+                                          total, H, W, stream), "aether_backproject")
+    else:
+        v, u = torch.meshgrid(torch.arange(H, device=device), torch.arange(W, device=device), indexing="ij")
+        pix = torch.stack([u.reshape(-1) + 0.5, v.reshape(-1) + 0.5, torch.ones(H * W, device=device)], 0).float().double()   # [3, HW]
+        step = 16
+        for i in range(0, total, step):
+            j = min(i + step, total)
+            depth = (1 / disp[i:j].clamp(1e-8, 1e8)).reshape(j - i, 1, H * W)
+            cam = (K_inv[i:j] @ pix) * depth                                                         # [n, 3, HW]
+            world = P[i:j, :, :3] @ cam + P[i:j, :, 3:]                                               # [n, 3, HW]
+            pointmaps[i:j] = world.transpose(1, 2).reshape(j - i, H, W, 3)
     return rgb.cpu().numpy(), disp.cpu().numpy(), poses, pointmaps.cpu().numpy()
+
+
+def _host(a):
+    return a.cpu().numpy() if isinstance(a, torch.Tensor) else a
 
 
 def blend_rgb(results: Sequence[WindowResult], total_frames: int) -> np.ndarray:

@@ -191,6 +191,24 @@ int aether_resample_pad(const void* x, int NB, int T, int H, int W, int C, int m
                         int ph, int pw, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Sliding-window merge on the device: the per-pixel part of blend_and_merge_window_results (scripts/demo.py:254-422) and of
+ * compute_scale / project (aether/utils/postprocess_utils.py:847-864, 393-403).  float64 arithmetic like the reference's numpy.
+ * ------------------------------------------------------------------------------------------------ */
+/* out3[0] = sum m*p*t, out3[1] = sum m*p*p (m = p > 0.1; fp32 products, float64 deterministic accumulation) over n pixels of the
+ * overlap, out3[2] = their ratio (0 when no pixel passes the mask).  pred fp32 = the new window's disparity, target float64 =
+ * the merged disparity so far.  scratch: >= 2 doubles per partial block (4096 doubles are plenty).  D:295-301. */
+int aether_merge_scale_fit(const float* pred, const double* target, long n, double* scratch, int scratch_doubles, double* out3, void* stream);
+/* One window [n_win, hw(,3)] fp32 into the merged float64 arrays (pointers at the window's first frame): the first `ov` frames are
+ * cross-faded with what is there (weights fade_host[f] for the merged frame, 1 - fade_host[f] for the window; host array of ov
+ * doubles = np.linspace(1, 0, ov)), the others are written; disparity is first multiplied by the device scalar *scale_dev
+ * (NULL: 1) as an fp32 product.  D:303-326. */
+int aether_merge_window(const float* w_rgb, const float* w_disp, double* rgb, double* disp, int n_win, int ov, long hw,
+                        const double* fade_host, const double* scale_dev, void* stream);
+/* World-space point map of N frames: out[n,v,u,:] = P[n][:3,:3] · (Kinv[n] · (u+.5, v+.5, 1) / clip(disp, 1e-8, 1e8)) + P[n][:3,3];
+ * Kinv float64 [N,3,3], P float64 [N,3,4] (camera-to-world), disp float64 [N,H,W], out float64 [N,H,W,3].  U:393-403. */
+int aether_backproject(const double* disp, const double* Kinv, const double* P, double* out, int N, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Whole-VAE entries (one call = AutoencoderKLCogVideoX.encode at P:557-618 / .decode through decode_latents at P:931,936,
  * with tiling and frame batching exactly as scripts/demo.py:229-230 enables them).  The launch plan (tile batches of equal
  * shape, frame chunks with threaded causal-conv caches, ResNets, resamplers, tile cross-fade) is C++ inside the library: pure

@@ -1,6 +1,9 @@
 """`aether.utils.postprocess_utils` — the names reference user code imports (scripts/demo.py:25-35, demo_gradio.py,
 evaluation/*/launch_aether.py) on top of aether_amd.geometry / aether_amd.export, with the reference's calling conventions:
-the camera-alignment helpers take and return torch tensors there (U:516-607), everything else numpy."""
+the camera-alignment helpers take and return torch tensors there (U:516-607), everything else numpy.
+Scope: the helpers on the sliding-window / evaluation-window path.  The reference's file-export and mesh
+utilities (depth_to_disparity, get_raymap_from_camera_parameters, save_ply, save_pointmap, depth_edge, align_rigid, get_pixel;
+aether.utils.visualize_utils.predictions_to_glb) are out of scope and raise a clear error when asked for."""
 import numpy as np
 import torch
 
@@ -45,3 +48,13 @@ def apply_transformation(cameras_src, align_t_R, align_t_T, align_t_s, return_ex
     """U:571-607."""
     out = torch.from_numpy(_G.apply_transformation(_np(cameras_src), _np(align_t_R), _np(align_t_T), float(align_t_s)))
     return out if return_extri else (out[..., :3], out[..., 3])
+
+
+_OUT_OF_SCOPE = ("depth_to_disparity", "get_raymap_from_camera_parameters", "save_ply", "save_pointmap", "depth_edge", "align_rigid", "get_pixel")
+
+
+def __getattr__(name):
+    if name in _OUT_OF_SCOPE:
+        raise AttributeError(f"aether.utils.postprocess_utils.{name} is a file-export / mesh helper of the reference that the MI355X hot-path "
+                             "build does not provide (SURVEY.md §2, out of scope); use the reference's own module for it")
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

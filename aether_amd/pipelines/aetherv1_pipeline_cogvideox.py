@@ -295,7 +295,9 @@ class AetherV1PipelineCogVideoX(_PipelineBase):
             return None
         t = torch.from_numpy(arr[:, top:top + ch, left:left + cw]).to(dev)
         if t.dtype == torch.uint8:
-            t = t.to(torch.float32) / 255.0
+            # a true fp32 division like the host path (`x.astype(float32) / 255.0`): dividing by a Python scalar makes the device
+            # kernel multiply by the rounded reciprocal, which is 1 ulp off for 126 of the 256 pixel values
+            t = torch.div(t.to(torch.float32), torch.full((), 255.0, dtype=torch.float32, device=t.device))
         t = 2.0 * t.permute(0, 3, 1, 2) - 1.0
         return t.to(torch.bfloat16).contiguous()
 

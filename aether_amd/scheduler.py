@@ -44,12 +44,18 @@ def _rescale_zero_terminal_snr(alphas_cumprod: torch.Tensor) -> torch.Tensor:
 
 
 class CogVideoXDPMScheduler:
+    """NOTE on defaults: a bare `CogVideoXDPMScheduler()` takes the values of THUDM/CogVideoX-5b's `scheduler/scheduler_config.json`
+    (what `from_pretrained` reads at /root/reference/scripts/demo.py:220-222: `snr_shift_scale` 1.0, `timestep_spacing`
+    "trailing", `prediction_type` "v_prediction", `rescale_betas_zero_snr` True), NOT diffusers' class-level defaults
+    (3.0, "leading", "epsilon", False).  Pass them explicitly to get the latter.  `trained_betas` is not supported (raises)."""
     order = 1
     _defaults = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
                      clip_sample=False, set_alpha_to_one=True, steps_offset=0, prediction_type="v_prediction",
                      timestep_spacing="trailing", rescale_betas_zero_snr=True, snr_shift_scale=1.0)
 
     def __init__(self, **config):
+        if config.get("trained_betas") is not None:
+            raise NotImplementedError("aether_amd: CogVideoXDPMScheduler(trained_betas=...) is not implemented")
         cfg = dict(self._defaults)
         cfg.update({k: v for k, v in config.items() if k in cfg})
         self.config = SimpleNamespace(**cfg)

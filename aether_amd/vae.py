@@ -152,6 +152,8 @@ class AetherVAE:
         self._handle = None
         self._workspace: Optional[torch.Tensor] = None
         self._ws_bytes: Optional[int] = None
+        self._graphs: Dict = {}
+        self.use_graphs = os.environ.get("AETHER_VAE_GRAPHS", "1") != "0"    # replay encode / decode from a captured hipGraph
 
     # ------------------------------------------------------------------------------------------------
     @classmethod
@@ -231,6 +233,7 @@ class AetherVAE:
             raise ValueError("aether_vae_create: " + self._lib.aether_last_error().decode())
         self._handle = h
         self._workspace = None
+        self._graphs.clear()
 
         def conv(name, cv: _Conv):
             kt, kh, kw = cv.ksize if len(cv.ksize) == 3 else ((1,) + tuple(cv.ksize) if len(cv.ksize) == 2 else (1, 1, 1))
@@ -273,26 +276,58 @@ class AetherVAE:
             pass
 
     def _run_c_plan(self, x: torch.Tensor, decode: bool) -> torch.Tensor:
-        """x [1, C, T, H, W] bf16 on the device -> [1, C_out, T_out, H_out, W_out] through ONE C call."""
+        """x [1, C, T, H, W] bf16 on the device -> [1, C_out, T_out, H_out, W_out] through ONE C call (replayed from a hipGraph
+        when `use_graphs`: the call only enqueues — ~4 700 kernels per decode — so its capture is valid for a fixed geometry,
+        workspace and static input / output buffers)."""
         src = x[0].contiguous()
         _, T, H, W = src.shape
         shp = [C.c_int() for _ in range(4)]
         _lib.check(self._lib.aether_vae_output_shape(self._handle, int(decode), T, H, W, *[C.byref(v) for v in shp]), "aether_vae_output_shape")
-        out = torch.empty(1, *[v.value for v in shp], dtype=torch.bfloat16, device=self.device)
+        oshape = (1, *[v.value for v in shp])
         need = self._lib.aether_vae_workspace_bytes(self._handle, int(decode), T, H, W, int(self.use_tiling))
         if need == 0:
             raise RuntimeError("aether_vae_workspace_bytes: " + self._lib.aether_last_error().decode())
         if self._workspace is None or self._workspace.numel() < need:
             # a fresh workspace resets the library's pool of zero-bordered volumes: leave head-room for the other direction's shapes
             self._workspace = None
+            self._graphs.clear()
             torch.cuda.empty_cache()
             old = 0 if self._ws_bytes is None else self._ws_bytes
             self._ws_bytes = max(int(need * 1.5), old + need) + (1 << 20)      # monotone: the pool of BOTH directions ends up fitting
             self._workspace = torch.empty(self._ws_bytes, dtype=torch.uint8, device=self.device)
         fn = self._lib.aether_vae_decode if decode else self._lib.aether_vae_encode
-        _lib.check(fn(self._handle, src.data_ptr(), T, H, W, int(self.use_tiling), out.data_ptr(), self._workspace.data_ptr(),
-                      self._workspace.numel(), self._stream()), "aether_vae_decode" if decode else "aether_vae_encode")
-        return out
+        what = "aether_vae_decode" if decode else "aether_vae_encode"
+
+        def call(src_t, out_t):
+            _lib.check(fn(self._handle, src_t.data_ptr(), T, H, W, int(self.use_tiling), out_t.data_ptr(), self._workspace.data_ptr(),
+                          self._workspace.numel(), self._stream()), what)
+
+        if not self.use_graphs or torch.cuda.is_current_stream_capturing():
+            out = torch.empty(oshape, dtype=torch.bfloat16, device=self.device)
+            call(src, out)
+            return out
+        key = (decode, T, H, W, bool(self.use_tiling))
+        ent = self._graphs.get(key)
+        if ent is None:
+            # first call of this geometry: eager (it also zeroes / fills what the pool needs); the second one is captured
+            self._graphs[key] = "seen"
+            out = torch.empty(oshape, dtype=torch.bfloat16, device=self.device)
+            call(src, out)
+            return out
+        if ent == "seen":
+            s_in, s_out = torch.empty_like(src), torch.empty(oshape, dtype=torch.bfloat16, device=self.device)
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, stream=side):
+                    call(s_in, s_out)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            ent = self._graphs[key] = (g, s_in, s_out)
+        g, s_in, s_out = ent
+        s_in.copy_(src)
+        g.replay()
+        return s_out.clone()
 
     def state_dict_spec(self) -> Dict[str, tuple]:
         """diffusers state-dict keys and shapes of an AutoencoderKLCogVideoX with this config."""

@@ -42,7 +42,9 @@ def seed_all(seed: int = 0) -> None:
 
 
 def parse_args(argv=None) -> argparse.Namespace:
-    p = argparse.ArgumentParser(description="AetherV1-CogvideoX Inference Demo")
+    p = argparse.ArgumentParser(description="AetherV1-CogvideoX Inference Demo", epilog="Multi-GPU (python -m torch.distributed.run --nproc-per-node N scripts/demo.py ...): "
+                                "reconstruction of a long video shards its sliding windows over all N ranks; a single guided clip (prediction / planning) uses "
+                                "ranks 0 and 1 for the two guidance branches and leaves ranks >= 2 idle.")
     p.add_argument("--task", type=str, required=True, choices=["reconstruction", "prediction", "planning"],
                    help="Task to perform: 'reconstruction', 'prediction' or 'planning'.")
     p.add_argument("--video", type=str, default=None, help="Path to a video file. Only used for 'reconstruction' task.")

@@ -65,6 +65,7 @@ SIGNATURES = {
     "aether_groupnorm_apply": (_i, [_vp, _i, _i, _i, _i, _i, _fp, _i, _vp, _i, _i, _i, _i, _i, _i, _fp, _i, _i, _i, C.POINTER(C.c_int), _vp]),
     "aether_causal_front": (_i, [_vp, _i, _i, C.c_long, _vp, _vp, _vp]),
     "aether_resample_pad": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "aether_preprocess_frames": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "aether_merge_scale_fit": (_i, [_fp, _vp, C.c_long, _vp, _i, _vp, _vp]),
     "aether_merge_window": (_i, [_fp, _fp, _vp, _vp, _i, _i, C.c_long, C.POINTER(C.c_double), _vp, _vp]),
     "aether_backproject": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

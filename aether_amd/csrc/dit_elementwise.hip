@@ -168,108 +168,104 @@ __global__ void unpatchify_kernel(const unsigned short* __restrict__ Y, int ldy,
 }
 
 // ------------------------------------------------------------------------------------------------
-// q/k LayerNorm(64) + RoPE + scale -> head-major Qh/Kh.  One block per token row; 8 lanes per (part, head).
+// ONE pass over the fused qkv projection: q/k LayerNorm(64) + 3-D RoPE (+ softmax scale on q) -> head-major Qh / Kh,
+// V -> V^T (through LDS), max ||k||^2 of the tile -> kmax2.  One workgroup per (64-token tile, batch·head): it reads the
+// three 64 x 64 blocks of its head out of the [B, S, 3·H·64] projection (128-byte row segments) and writes three 8 KiB
+// tiles.  Round 1 did this in two kernels (q/k rows, then V transpose + a re-read of Kh for the norms: 648 MB of traffic per
+// layer at S = 15 076); fused it moves each element once in, once out (554 MB).
 // ------------------------------------------------------------------------------------------------
 struct QkArgs {
-    const bf16_t* qkv; int S, H, n_text;
+    const bf16_t* qkv; int S, H, n_text, Spad;
     const float* qn_w; const float* qn_b; const float* kn_w; const float* kn_b; float eps;
     const float* cos_t; const float* sin_t; float q_scale;
-    bf16_t* Qh; bf16_t* Kh;
+    bf16_t* Qh; bf16_t* Kh; unsigned short* Vt; float* kmax2;
 };
 
-__global__ __launch_bounds__(256) void qk_norm_rope_kernel(QkArgs p) {
-    const int row = blockIdx.x;              // b*S + s
-    const int b = row / p.S, s = row - b * p.S;
-    const int HD = p.H * 64;
-    const bf16_t* src = p.qkv + (size_t)row * 3 * HD;
-    const int items = 2 * p.H * 8;
-    const int vtok = s - p.n_text;
-    for (int it = threadIdx.x; it < items; it += 256) {
-        const int part = it / (p.H * 8);
-        const int rem = it - part * p.H * 8;
-        const int h = rem >> 3, sub = rem & 7;
-        const u16x8 raw = *(const u16x8*)(src + part * HD + h * 64 + sub * 8);
-        float v[8];
-        float sum = 0.f;
+// LayerNorm(64) of one head row spread over 8 lanes (8 values each) + affine + RoPE (adjacent pairs) + scale, rounded to bf16
+AE_DEV uint4 qk_row(const u16x8 raw, const float* __restrict__ nw, const float* __restrict__ nb, float eps, const float* __restrict__ cs,
+                    const float* __restrict__ sn, float sc) {
+    float v[8];
+    float sum = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { v[e] = bf16_bits_to_f32(raw[e]); sum += v[e]; }
-        sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64);
-        const float mean = sum * (1.0f / 64.0f);
-        float sq = 0.f;
+    for (int e = 0; e < 8; ++e) { v[e] = bf16_bits_to_f32(raw[e]); sum += v[e]; }
+    sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64);
+    const float mean = sum * (1.0f / 64.0f);
+    float sq = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; sq += d * d; }
-        sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
-        const float rstd = rsqrtf(sq * (1.0f / 64.0f) + p.eps);
-        const float* nw = (part == 0 ? p.qn_w : p.kn_w) + sub * 8;
-        const float* nb = (part == 0 ? p.qn_b : p.kn_b) + sub * 8;
+    for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; sq += d * d; }
+    sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
+    const float rstd = rsqrtf(sq * (1.0f / 64.0f) + eps);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean) * rstd * nw[e] + nb[e];
-        if (vtok >= 0) {
-            const float* cs = p.cos_t + (size_t)vtok * 64 + sub * 8;
-            const float* sn = p.sin_t + (size_t)vtok * 64 + sub * 8;
+    for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean) * rstd * nw[e] + nb[e];
+    if (cs != nullptr) {
 #pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                const float x0 = v[e], x1 = v[e + 1];
-                v[e] = x0 * cs[e] - x1 * sn[e];
-                v[e + 1] = x1 * cs[e + 1] + x0 * sn[e + 1];
-            }
+        for (int e = 0; e < 8; e += 2) {
+            const float x0 = v[e], x1 = v[e + 1];
+            v[e] = x0 * cs[e] - x1 * sn[e];
+            v[e + 1] = x1 * cs[e + 1] + x0 * sn[e + 1];
         }
-        const float sc = (part == 0) ? p.q_scale : 1.0f;
-        uint4 out = make_uint4(pack_bf16x2(v[0] * sc, v[1] * sc), pack_bf16x2(v[2] * sc, v[3] * sc),
-                               pack_bf16x2(v[4] * sc, v[5] * sc), pack_bf16x2(v[6] * sc, v[7] * sc));
-        bf16_t* dst = (part == 0 ? p.Qh : p.Kh) + (((size_t)b * p.H + h) * p.S + s) * 64 + sub * 8;
-        *(uint4*)dst = out;
     }
+    return make_uint4(pack_bf16x2(v[0] * sc, v[1] * sc), pack_bf16x2(v[2] * sc, v[3] * sc), pack_bf16x2(v[4] * sc, v[5] * sc),
+                      pack_bf16x2(v[6] * sc, v[7] * sc));
 }
 
-// V[b,s,h,:] (inside qkv) -> Vt[b,h,d,s]; 64x64 tile through LDS; pad columns (s >= S) written as zero.
-// The same (64-token, head) blocks also reduce max ||k||^2 over their tile of the freshly written head-major Kh (8 KB,
-// contiguous, still cache resident) into kmax2[(b*H + h)*(Spad/64) + tile]: plain stores, no atomics (236 same-address
-// atomics per head cost ~60 us a layer), on the bf16 values attention will read; attention takes the max over the tiles.
-__global__ __launch_bounds__(256) void v_transpose_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ Vt,
-                                                          int S, int H, int Spad, const unsigned short* __restrict__ Kh,
-                                                          float* __restrict__ kmax2) {
+__global__ __launch_bounds__(256) void qkv_prepare_kernel(QkArgs p) {
     __shared__ unsigned short tile[64][66];
     __shared__ float wmax[4];
-    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
     const int s0 = blockIdx.x * 64;
-    const int HD = H * 64;
+    const int HD = p.H * 64;
     const int tid = threadIdx.x;
     float kmx = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int piece = tid + i * 256;  // 512 pieces of 16 B: s_local = piece/8, chunk = piece%8
+        const int piece = tid + i * 256;          // 512 pieces of 16 B per 64 x 64 block: token = piece/8, chunk = piece%8
         const int sl = piece >> 3, ch = piece & 7;
-        u16x8 raw = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (s0 + sl < S) raw = *(const u16x8*)(qkv + ((size_t)b * S + s0 + sl) * 3 * HD + 2 * HD + h * 64 + ch * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) tile[ch * 8 + e][sl] = raw[e];
-        if (kmax2 != nullptr) {   // token s0+sl of Kh: its 64 elements sit in the 8 lanes sharing `sl`
-            float n2 = 0.f;
-            if (s0 + sl < S) {
-                const u16x8 kr = *(const u16x8*)(Kh + ((size_t)bh * S + s0 + sl) * 64 + ch * 8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { const float kv = bf16_bits_to_f32(kr[e]); n2 += kv * kv; }
-            }
-            n2 += __shfl_xor(n2, 1, 64); n2 += __shfl_xor(n2, 2, 64); n2 += __shfl_xor(n2, 4, 64);
-            kmx = fmaxf(kmx, n2);
+        const int s = s0 + sl;
+        const bool ok = s < p.S;
+        const bf16_t* row = p.qkv + ((size_t)b * p.S + (ok ? s : p.S - 1)) * 3 * HD + h * 64 + ch * 8;
+        const int vtok = s - p.n_text;
+        const float* cs = (ok && vtok >= 0) ? p.cos_t + (size_t)vtok * 64 + ch * 8 : nullptr;
+        const float* sn = (ok && vtok >= 0) ? p.sin_t + (size_t)vtok * 64 + ch * 8 : nullptr;
+        const uint4 q = qk_row(*(const u16x8*)row, p.qn_w + ch * 8, p.qn_b + ch * 8, p.eps, cs, sn, p.q_scale);
+        const uint4 k = qk_row(*(const u16x8*)(row + HD), p.kn_w + ch * 8, p.kn_b + ch * 8, p.eps, cs, sn, 1.0f);
+        u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (ok) {
+            v = *(const u16x8*)(row + 2 * HD);
+            const size_t o = (((size_t)b * p.H + h) * p.S + s) * 64 + ch * 8;
+            *(uint4*)(p.Qh + o) = q;
+            *(uint4*)(p.Kh + o) = k;
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tile[ch * 8 + e][sl] = v[e];
+        // ||k||^2 of the rounded bf16 key (what attention reads): the 64 elements of a token sit in the 8 lanes sharing `sl`
+        float n2 = 0.f;
+        if (ok) {
+            const unsigned kw[4] = {k.x, k.y, k.z, k.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float lo = __uint_as_float(kw[e] << 16), hi2 = __uint_as_float(kw[e] & 0xffff0000u);
+                n2 += lo * lo; n2 += hi2 * hi2;
+            }
+        }
+        n2 += __shfl_xor(n2, 1, 64); n2 += __shfl_xor(n2, 2, 64); n2 += __shfl_xor(n2, 4, 64);
+        kmx = fmaxf(kmx, n2);
     }
-    if (kmax2 != nullptr) {
+    if (p.kmax2 != nullptr) {
         kmx = wave_max(kmx);
         if ((tid & 63) == 0) wmax[tid >> 6] = kmx;
     }
     __syncthreads();
-    if (kmax2 != nullptr && tid == 0)
-        kmax2[(size_t)bh * gridDim.x + blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    if (p.kmax2 != nullptr && tid == 0)
+        p.kmax2[(size_t)bh * gridDim.x + blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int piece = tid + i * 256;  // d = piece/8, s chunk = piece%8
+        const int piece = tid + i * 256;          // d = piece/8, token chunk = piece%8; pad columns (s >= S) are zero
         const int d = piece >> 3, ch = piece & 7;
         u16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = tile[d][ch * 8 + e];
-        *(u16x8*)(Vt + ((size_t)bh * 64 + d) * Spad + s0 + ch * 8) = o;
+        *(u16x8*)(p.Vt + ((size_t)bh * 64 + d) * p.Spad + s0 + ch * 8) = o;
     }
 }
 
@@ -345,11 +341,8 @@ extern "C" int aether_qk_norm_rope(const void* qkv, int B, int S, int H, int n_t
     if (B <= 0 || S <= 0 || H <= 0 || n_text < 0 || n_text > S) return aether_set_error(AETHER_ERR_SHAPE, "qk_norm_rope: bad shape");
     if (n_text < S && (!cos_t || !sin_t)) return aether_set_error(AETHER_ERR_ARG, "qk_norm_rope: rope tables required");
     if (Spad % 64 != 0 || Spad < S) return aether_set_error(AETHER_ERR_SHAPE, "qk_norm_rope: Spad must be roundup(S,64)");
-    QkArgs p{(const bf16_t*)qkv, S, H, n_text, qn_w, qn_b, kn_w, kn_b, eps, cos_t, sin_t, q_scale, (bf16_t*)Qh, (bf16_t*)Kh};
-    hipLaunchKernelGGL(qk_norm_rope_kernel, dim3(B * S), dim3(256), 0, AE_STREAM, p);
-    int rc = aether_check_launch("qk_norm_rope");
-    if (rc) return rc;
-    hipLaunchKernelGGL(v_transpose_kernel, dim3(Spad / 64, B * H), dim3(256), 0, AE_STREAM, (const unsigned short*)qkv,
-                       (unsigned short*)Vt, S, H, Spad, (const unsigned short*)Kh, kmax2);
-    return aether_check_launch("v_transpose");
+    QkArgs p{(const bf16_t*)qkv, S, H, n_text, Spad, qn_w, qn_b, kn_w, kn_b, eps, cos_t, sin_t, q_scale, (bf16_t*)Qh, (bf16_t*)Kh,
+             (unsigned short*)Vt, kmax2};
+    hipLaunchKernelGGL(qkv_prepare_kernel, dim3(Spad / 64, B * H), dim3(256), 0, AE_STREAM, p);
+    return aether_check_launch("qkv_prepare");
 }

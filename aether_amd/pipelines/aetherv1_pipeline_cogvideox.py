@@ -283,14 +283,24 @@ class AetherV1PipelineCogVideoX(_PipelineBase):
         return self.video_processor.preprocess(frames, height, width)
 
     def _preprocess_frames_on_device(self, frames, height, width, dev):
-        """Same values as `_preprocess_image(...).to(dev, bfloat16)` for an [N,H,W,C] / [H,W,C] uint8 / float32 / float64 array whose
-        centred crop window (preprocess_utils.py:4-39) lies inside the frame and already has the target size: the cropped VIEW
-        is uploaded once and /255, 2x-1 (fp32, the same two IEEE operations as the host path), NHWC->NCHW and the bf16 rounding
-        run on the device instead of as four host passes over the clip.  Returns None when the fast path does not apply."""
+        """Same values as `_preprocess_image(...).to(dev, bfloat16)` for an [N,H,W,C] / [H,W,C] array, computed on the device from ONE
+        upload of the raw frames.  On an MI355X uint8 / float32 clips of ANY size go through `aether_preprocess_frames` (/255,
+        imcrop_center's window incl. zero fill, nearest resize with PyTorch's index rule, 2x-1, NHWC->NCHW, bf16 — one kernel).
+        Elsewhere (CPU tests) and for float64 clips the no-resize case runs as torch operations (the same IEEE operations as the
+        host path).  Returns None when neither applies (the caller falls back to the reference's host path)."""
         if isinstance(frames, torch.Tensor) or frames.dtype not in (np.uint8, np.float32, np.float64) or frames.ndim not in (3, 4):
             return None
         arr = frames[None] if frames.ndim == 3 else frames
         top, left, ch, cw = crop_window(arr.shape[1], arr.shape[2], height, width)
+        dev = torch.device(dev)
+        if dev.type == "cuda" and arr.dtype in (np.uint8, np.float32) and ch > 0 and cw > 0:
+            from .. import _lib
+            src = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
+            out = torch.empty(arr.shape[0], arr.shape[3], height, width, dtype=torch.bfloat16, device=dev)
+            _lib.check(_lib.load().aether_preprocess_frames(src.data_ptr(), int(arr.dtype == np.uint8), arr.shape[0], arr.shape[1], arr.shape[2],
+                                                            arr.shape[3], top, left, ch, cw, height, width, out.data_ptr(),
+                                                            torch.cuda.current_stream(dev).cuda_stream), "aether_preprocess_frames")
+            return out
         if (ch, cw) != (height, width) or top < 0 or left < 0 or top + ch > arr.shape[1] or left + cw > arr.shape[2]:
             return None
         t = torch.from_numpy(arr[:, top:top + ch, left:left + cw]).to(dev)

@@ -191,6 +191,16 @@ int aether_resample_pad(const void* x, int NB, int T, int H, int W, int C, int m
                         int ph, int pw, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Input preprocessing on the device: the array branch of `_preprocess_image` (P:451-460) fused into one pass — uint8 / 255,
+ * imcrop_center's centred window (preprocess_utils.py:4-39, zero fill outside the frame), nearest resize with PyTorch's index
+ * rule (VideoProcessor.preprocess -> F.interpolate(size=...)), 2x - 1, NHWC -> NCHW, one rounding to bf16.
+ * src [N, Hs, Ws, C] uint8 (is_u8 != 0) or float32 on the device; (top, left, ch, cw) = the crop window in source pixels
+ * (aether_amd/preprocess.py::crop_window); out bf16 [N, C, H, W].
+ * ------------------------------------------------------------------------------------------------ */
+int aether_preprocess_frames(const void* src, int is_u8, int N, int Hs, int Ws, int C, int top, int left, int ch, int cw, int H, int W,
+                             void* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Sliding-window merge on the device: the per-pixel part of blend_and_merge_window_results (scripts/demo.py:254-422) and of
  * compute_scale / project (aether/utils/postprocess_utils.py:847-864, 393-403).  float64 arithmetic like the reference's numpy.
  * ------------------------------------------------------------------------------------------------ */

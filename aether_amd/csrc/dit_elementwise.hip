@@ -181,9 +181,10 @@ struct QkArgs {
     bf16_t* Qh; bf16_t* Kh; unsigned short* Vt; float* kmax2;
 };
 
-// LayerNorm(64) of one head row spread over 8 lanes (8 values each) + affine + RoPE (adjacent pairs) + scale, rounded to bf16
-AE_DEV uint4 qk_row(const u16x8 raw, const float* __restrict__ nw, const float* __restrict__ nb, float eps, const float* __restrict__ cs,
-                    const float* __restrict__ sn, float sc) {
+// LayerNorm(64) of one head row spread over 8 lanes (8 values each) + affine + RoPE (adjacent pairs) + scale, rounded to bf16;
+// every operand is already in registers (all loads of the workgroup are issued up front: one memory round trip, not eight)
+AE_DEV uint4 qk_row(const u16x8 raw, const f32x4 (&nw)[2], const f32x4 (&nb)[2], float eps, const f32x4 (&cs)[2], const f32x4 (&sn)[2], bool rope,
+                    float sc) {
     float v[8];
     float sum = 0.f;
 #pragma unroll
@@ -196,13 +197,13 @@ AE_DEV uint4 qk_row(const u16x8 raw, const float* __restrict__ nw, const float* 
     sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
     const float rstd = rsqrtf(sq * (1.0f / 64.0f) + eps);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean) * rstd * nw[e] + nb[e];
-    if (cs != nullptr) {
+    for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean) * rstd * nw[e >> 2][e & 3] + nb[e >> 2][e & 3];
+    if (rope) {
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
             const float x0 = v[e], x1 = v[e + 1];
-            v[e] = x0 * cs[e] - x1 * sn[e];
-            v[e + 1] = x1 * cs[e + 1] + x0 * sn[e + 1];
+            v[e] = x0 * cs[e >> 2][e & 3] - x1 * sn[e >> 2][e & 3];
+            v[e + 1] = x1 * cs[(e + 1) >> 2][(e + 1) & 3] + x0 * sn[(e + 1) >> 2][(e + 1) & 3];
         }
     }
     return make_uint4(pack_bf16x2(v[0] * sc, v[1] * sc), pack_bf16x2(v[2] * sc, v[3] * sc), pack_bf16x2(v[4] * sc, v[5] * sc),
@@ -212,39 +213,60 @@ AE_DEV uint4 qk_row(const u16x8 raw, const float* __restrict__ nw, const float* 
 __global__ __launch_bounds__(256) void qkv_prepare_kernel(QkArgs p) {
     __shared__ unsigned short tile[64][66];
     __shared__ float wmax[4];
-    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
-    const int s0 = blockIdx.x * 64;
+    // head fastest in the grid: the workgroups running together cover the same 64 token rows across all heads, i.e. whole
+    // contiguous 18 KiB rows of the projection between them
+    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+    const int s0 = blockIdx.y * 64;
     const int HD = p.H * 64;
     const int tid = threadIdx.x;
+    const int ch = tid & 7;                       // 16-byte chunk of the 128-byte head row (the same in both passes)
+    // ---- every load of this thread, issued before anything is consumed ------------------------------------------------------------
+    u16x8 rq[2], rk[2], rv[2];
+    f32x4 cs[2][2], sn[2][2];
+    bool ok[2], rope[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int s = s0 + (tid >> 3) + 32 * i;   // token of piece tid + 256 i
+        ok[i] = s < p.S;
+        const bf16_t* row = p.qkv + ((size_t)b * p.S + (ok[i] ? s : p.S - 1)) * 3 * HD + h * 64 + ch * 8;
+        rq[i] = *(const u16x8*)row;
+        rk[i] = *(const u16x8*)(row + HD);
+        rv[i] = *(const u16x8*)(row + 2 * HD);
+        const int vtok = s - p.n_text;
+        rope[i] = ok[i] && vtok >= 0;
+        const size_t to = (size_t)(rope[i] ? vtok : 0) * 64 + ch * 8;     // (n_text == S: no table; never dereferenced then)
+        if (p.cos_t != nullptr) {
+            cs[i][0] = *(const f32x4*)(p.cos_t + to); cs[i][1] = *(const f32x4*)(p.cos_t + to + 4);
+            sn[i][0] = *(const f32x4*)(p.sin_t + to); sn[i][1] = *(const f32x4*)(p.sin_t + to + 4);
+        }
+    }
+    f32x4 qw[2], qb[2], kw[2], kb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        qw[j] = *(const f32x4*)(p.qn_w + ch * 8 + 4 * j); qb[j] = *(const f32x4*)(p.qn_b + ch * 8 + 4 * j);
+        kw[j] = *(const f32x4*)(p.kn_w + ch * 8 + 4 * j); kb[j] = *(const f32x4*)(p.kn_b + ch * 8 + 4 * j);
+    }
     float kmx = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int piece = tid + i * 256;          // 512 pieces of 16 B per 64 x 64 block: token = piece/8, chunk = piece%8
-        const int sl = piece >> 3, ch = piece & 7;
+        const int sl = (tid >> 3) + 32 * i;
         const int s = s0 + sl;
-        const bool ok = s < p.S;
-        const bf16_t* row = p.qkv + ((size_t)b * p.S + (ok ? s : p.S - 1)) * 3 * HD + h * 64 + ch * 8;
-        const int vtok = s - p.n_text;
-        const float* cs = (ok && vtok >= 0) ? p.cos_t + (size_t)vtok * 64 + ch * 8 : nullptr;
-        const float* sn = (ok && vtok >= 0) ? p.sin_t + (size_t)vtok * 64 + ch * 8 : nullptr;
-        const uint4 q = qk_row(*(const u16x8*)row, p.qn_w + ch * 8, p.qn_b + ch * 8, p.eps, cs, sn, p.q_scale);
-        const uint4 k = qk_row(*(const u16x8*)(row + HD), p.kn_w + ch * 8, p.kn_b + ch * 8, p.eps, cs, sn, 1.0f);
-        u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (ok) {
-            v = *(const u16x8*)(row + 2 * HD);
+        const uint4 q = qk_row(rq[i], qw, qb, p.eps, cs[i], sn[i], rope[i], p.q_scale);
+        const uint4 k = qk_row(rk[i], kw, kb, p.eps, cs[i], sn[i], rope[i], 1.0f);
+        if (ok[i]) {
             const size_t o = (((size_t)b * p.H + h) * p.S + s) * 64 + ch * 8;
             *(uint4*)(p.Qh + o) = q;
             *(uint4*)(p.Kh + o) = k;
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) tile[ch * 8 + e][sl] = v[e];
+        for (int e = 0; e < 8; ++e) tile[ch * 8 + e][sl] = ok[i] ? rv[i][e] : (unsigned short)0;
         // ||k||^2 of the rounded bf16 key (what attention reads): the 64 elements of a token sit in the 8 lanes sharing `sl`
         float n2 = 0.f;
-        if (ok) {
-            const unsigned kw[4] = {k.x, k.y, k.z, k.w};
+        if (ok[i]) {
+            const unsigned kwd[4] = {k.x, k.y, k.z, k.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float lo = __uint_as_float(kw[e] << 16), hi2 = __uint_as_float(kw[e] & 0xffff0000u);
+                const float lo = __uint_as_float(kwd[e] << 16), hi2 = __uint_as_float(kwd[e] & 0xffff0000u);
                 n2 += lo * lo; n2 += hi2 * hi2;
             }
         }
@@ -257,7 +279,7 @@ __global__ __launch_bounds__(256) void qkv_prepare_kernel(QkArgs p) {
     }
     __syncthreads();
     if (p.kmax2 != nullptr && tid == 0)
-        p.kmax2[(size_t)bh * gridDim.x + blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        p.kmax2[(size_t)bh * gridDim.y + blockIdx.y] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int piece = tid + i * 256;          // d = piece/8, token chunk = piece%8; pad columns (s >= S) are zero
@@ -343,6 +365,6 @@ extern "C" int aether_qk_norm_rope(const void* qkv, int B, int S, int H, int n_t
     if (Spad % 64 != 0 || Spad < S) return aether_set_error(AETHER_ERR_SHAPE, "qk_norm_rope: Spad must be roundup(S,64)");
     QkArgs p{(const bf16_t*)qkv, S, H, n_text, Spad, qn_w, qn_b, kn_w, kn_b, eps, cos_t, sin_t, q_scale, (bf16_t*)Qh, (bf16_t*)Kh,
              (unsigned short*)Vt, kmax2};
-    hipLaunchKernelGGL(qkv_prepare_kernel, dim3(Spad / 64, B * H), dim3(256), 0, AE_STREAM, p);
+    hipLaunchKernelGGL(qkv_prepare_kernel, dim3(B * H, Spad / 64), dim3(256), 0, AE_STREAM, p);
     return aether_check_launch("qkv_prepare");
 }

@@ -168,8 +168,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
         //   group 0 (waves 0-3):  L0 C0 L1 C1 L2 C2 L3 C3        group 1 (waves 4-7):  C3' L0 C0 L1 C1 L2 C2 L3
         // (C3' = last compute slot of the previous tile); KSPS = 2 halves the number of slots (16 MFMAs per slot).
         // The matrix pipe of every SIMD always has exactly one wave feeding it; the loading wave also issues the LDS-DMA.
-        auto pingpong = [&](auto ksps_tag) {
+        auto pingpong = [&](auto ksps_tag, auto spread_tag) {
             constexpr int KSPS = decltype(ksps_tag)::value;
+            // SPREAD (KSPS = 1 only): the early group (waves 0-3) issues its 8 DMA pieces of the next tile 2/2/2/2 over its four load
+            // slots instead of 3/3/2/0 — its last pieces have the whole last compute slot to land before the vmcnt(0) that ends the
+            // tile; the late group (its tile ends WITH its last load slot) keeps 3/3/2.  A load slot with three pieces outlasts the
+            // partner's 256-cycle compute slot (60-185 cycles per piece), two fit.
+            constexpr bool SPREAD = decltype(spread_tag)::value;
             constexpr int NSLOT = 4 / KSPS;            // compute slots per K tile
             bf16x8 wf[KSPS][NT], xf[KSPS][MT];
             auto load_frags = [&](const char* base, int slot) {
@@ -183,6 +188,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
             };
             // DMA pieces of tile kt split in NPART parts, one per early compute slot
             constexpr int NPART = (KSPS == 1) ? 3 : 1;
+            constexpr int NPART0 = (KSPS == 1 && SPREAD) ? 4 : NPART;      // early group
             // past the last K tile the staging re-fetches that tile into the buffer nobody reads any more: no branch around
             // the DMA pieces, uniform vmcnt accounting
             // gathered A: the tap offset of the tile being staged was fetched (scalar load) one tile earlier — a load issued
@@ -192,7 +198,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
             // it as its scalar offset in a waterfall loop)
             int tap_stage = GATHER ? __builtin_amdgcn_readfirstlane(p.tap_off[min(1, nk - 1) + k_first]) : 0;   // tile staged during tile 0
             int tap_ahead = 0;
-            auto stage_part = [&](int kt, int buf, int part) {
+            auto stage_part = [&](int kt, int buf, int part, auto nparts_tag) {
+                constexpr int NPART = decltype(nparts_tag)::value;
                 kt = min(kt, nk - 1) + k_first;
                 const unsigned a_soff = 2u * (unsigned)(GATHER ? tap_stage : kt * GEMM_BK), w_soff = 2u * (unsigned)(kt * GEMM_BK);
                 char* dst = lds_stage + buf * BUF_BYTES;
@@ -236,7 +243,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
                     for (int sl = 0; sl < NSLOT; ++sl) {
                         load_frags(base, sl);
-                        if (sl < NPART) stage_part(kt + 1, (kt + 1) & 1, sl);
+                        if (sl < NPART0) stage_part(kt + 1, (kt + 1) & 1, sl, std::integral_constant<int, NPART0>{});
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         slot_end();
                         mma();
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
                     for (int sl = 0; sl < NSLOT; ++sl) {
                         load_frags(base, sl);
-                        if (sl < NPART) stage_part(kt + 1, (kt + 1) & 1, sl);
+                        if (sl < NPART) stage_part(kt + 1, (kt + 1) & 1, sl, std::integral_constant<int, NPART>{});
                         if (sl == NSLOT - 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         slot_end();
@@ -268,8 +275,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
                 mma();                                             // last compute slot of the last tile
             }
         };
-        if (p.stagger == 1) pingpong(std::integral_constant<int, 1>{});
-        else pingpong(std::integral_constant<int, 2>{});
+        if (p.stagger == 1) pingpong(std::integral_constant<int, 1>{}, std::false_type{});
+        else if (p.stagger == 3) pingpong(std::integral_constant<int, 1>{}, std::true_type{});
+        else pingpong(std::integral_constant<int, 2>{}, std::false_type{});
     } else
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;

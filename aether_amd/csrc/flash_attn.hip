@@ -37,6 +37,8 @@
 
 namespace aether {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int FA_QBLK = 256, FA_KVBLK = 64, FA_D = 64;
 constexpr int FA_TILE = FA_KVBLK * FA_D * 2;  // 8 KiB (K tile) == 8 KiB (Vᵀ tile)
 constexpr int FA_BUF = 2 * FA_TILE;
@@ -375,6 +377,8 @@ void flash_attn_fwd_kernel(FlashArgs p) {
         auto Vf = [&](int dt, int t, int s2) { return *(const bf16x8*)(base + dt * 4096 + L.voff[t][s2]); };
         f32x16 s0, s1;
         bf16x8 pf[2][2];
+        // (row sums as v_pk_fma_f32 with a register of ones — 6 cycles per two elements in isolation — measured 3 % SLOWER here than
+        // plain v_add_f32, as in round 1's lock-step kernel: profiles/r02_attn_variants.txt)
         float ps[4] = {0.f, 0.f, 0.f, 0.f};
         // one quarter (4 scores) of a 32-key half: exp2, row sum, bf16 P fragment elements
         auto quarter = [&](const f32x16& sc, int t, int q) {
@@ -460,7 +464,6 @@ void flash_attn_fwd_kernel(FlashArgs p) {
 constexpr int FA_NB = 4;  // K/V ring depth (tile t lives in slot t & 3)
 
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <int I> using ic = std::integral_constant<int, I>;

@@ -21,6 +21,7 @@ AETHER_ATTN_PIPELINED = 16    # attention: software-pipelined kernel
 AETHER_ATTN_EXACT_MAX = 32    # attention: ignore the score bound, always run the exact online soft-max
 AETHER_ATTN_TAIL_SPLIT = 64   # attention: the partly filled last round runs as 128-row workgroups (second launch)
 AETHER_ATTN_INTERLEAVE = 256  # attention: steady-state tiles interleave soft-max VALU with the wave's own MFMAs
+AETHER_ATTN_PAIR_PIPELINE = 512   # attention: bounded workgroups run two tiles per iteration (soft-max spread over 24 of 32 MFMAs)
 AETHER_CONV_TAP_REUSE = 128   # conv: K order is (dt, dh, channel block, dw) -> the tap-reuse kernel may be used
 ATTN_Q_SCALE = 0.125 * 1.4426950408889634   # softmax scale x log2(e): the attention kernel works in the log2 domain
 PROF_CLASSES = ["other", "layernorm", "gemm_qkv", "qk_norm_rope", "attention", "gemm_out", "gemm_ff1", "gemm_ff2"]

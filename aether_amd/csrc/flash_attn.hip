@@ -174,6 +174,10 @@ AE_DEV void fa_store(const f32x16 (&o)[2], float l_run, const FlashArgs& p, int 
     }
 }
 
+template <int I> using ic = std::integral_constant<int, I>;
+template <class F, int... Is> AE_DEV void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(ic<Is>{}), ...); }
+template <int N, class F> AE_DEV void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 // ---- guarded static shift (the lock-step kernel's soft-max; exact, shift-invariant) -----------------------------------
 // Soft-max is invariant under ANY per-row shift c:  o = Σ exp2(s−c)·v / Σ exp2(s−c).  The online algorithm uses c = the
 // running maximum only to keep exp2 in range.  Here the shift of a row is a value m that is a TRUE score maximum of the tiles
@@ -368,7 +372,7 @@ void flash_attn_fwd_kernel(FlashArgs p) {
         if (!LAST) drain_and_barrier();
     };
     // ---- interleaved steady-state tile (guard already checked, not the last tile) ---------------------------------------
-    auto tile_ilv = [&](int j) {
+    [[maybe_unused]] auto tile_ilv = [&](int j) {
         const int cur = j & 1;
         stage(j + 1, cur ^ 1);
         const char* base = smem + cur * FA_BUF;
@@ -431,7 +435,154 @@ void flash_attn_fwd_kernel(FlashArgs p) {
         l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
         drain_and_barrier();
     };
-    if (ILV != 0) {
+    // ---- ILV = 2: two tiles per iteration, soft-max of each 32-key half spread over the MFMAs of its neighbours -----------------------
+    // Per pair of tiles (halves h0,h1 of tile j, h2,h3 of tile j+1) the wave issues, in this order (MFMA group ∥ VALU it hides):
+    //   QK h0 | QK h1 ∥ sm h0 a | QK h2 ∥ sm h0 b | PV h0 ∥ sm h1 a | QK h3 ∥ sm h1 b | PV h1 ∥ sm h2 a | X | sm h2 b | PV h2 ∥ sm h3 a | sm h3 b | PV h3 | Y
+    // so 24 of the 32 MFMAs run with ~40 cycles of the wave's own soft-max VALU behind each of them (the one-tile variant pairs
+    // 8 of 16); ≈ 730 issue cycles per tile against ≈ 860.  Three score halves are live at the peak, which leaves no room for the
+    // shift vector: the loop runs only when EVERY wave of the workgroup is bounded outright (||q||·max||k|| <= 100 over the whole
+    // head: exp2(s) cannot overflow with shift 0) — its barriers (X: tile j and K(j+1) consumed -> DMA of K,V(j+2), K(j+3);
+    // Y: V(j+1) consumed -> DMA of V(j+3)) differ from the one-per-tile pattern, so the choice must be workgroup-uniform.  Any other
+    // workgroup takes the guarded one-tile paths above.
+    [[maybe_unused]] auto stage_k = [&](int j, int buf) {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps)
+            bglds16(k_rsrc, k_voff + ps * (NW * 8) * (FA_D * 2), j * (FA_KVBLK * FA_D * 2), lds_stage + buf * FA_BUF + ps * (NW * 1024));
+    };
+    [[maybe_unused]] auto stage_v = [&](int j, int buf) {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps)
+            bglds16(v_rsrc, v_voff + ps * (NW * 8) * (unsigned)p.Spad * 2, j * (FA_KVBLK * 2), lds_stage + buf * FA_BUF + FA_TILE + ps * (NW * 1024));
+    };
+    [[maybe_unused]] auto pair_loop = [&](int npairs) {
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
+        // K(1) -> buffer 1 now, V(1) after the barrier that publishes it (K(0), V(0) were staged and published by the prologue)
+        stage_k(1, 1);
+        drain_and_barrier();
+        stage_v(1, 1);
+        for (int pi = 0; pi < npairs; ++pi) {
+            const int j = 2 * pi;
+            f32x16 S[4];
+            bf16x8 pf[4][2];
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            // A-operand fragment of MFMA step i (0..31): QK h0 0-3, QK h1 4-7, QK h2 8-11, PV h0 12-15, QK h3 16-19, PV h1 20-23, PV h2 24-27, PV h3 28-31
+            auto afrag = [&](auto I) -> bf16x8 {
+                constexpr int i = decltype(I)::value;
+                constexpr int grp = i >> 2, m = i & 3;
+                constexpr int h = (grp == 0) ? 0 : (grp == 1) ? 1 : (grp == 2) ? 2 : (grp == 3) ? 0 : (grp == 4) ? 3 : (grp == 5) ? 1 : (grp == 6) ? 2 : 3;
+                constexpr bool qk = (grp == 0 || grp == 1 || grp == 2 || grp == 4);
+                const char* base = smem + (h >> 1) * FA_BUF;              // tile j in buffer 0, tile j+1 in buffer 1 (j is even)
+                if constexpr (qk) return *(const bf16x8*)(base + (h & 1) * 4096 + L.koff[m]);
+                else return *(const bf16x8*)(base + (m & 1) * 4096 + L.voff[h & 1][m >> 1]);      // dt = m&1, s2 = m>>1
+            };
+            // one eighth (2 scores) of a half's soft-max
+            auto eighth = [&](auto H, auto E) {
+                constexpr int h = decltype(H)::value, e = decltype(E)::value;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float pv = __builtin_amdgcn_exp2f(S[h][2 * e + u]);
+                    ps[2 * (e & 1) + u] += pv;
+                    asm volatile("" : "+v"(ps[2 * (e & 1) + u]));
+                    pf[h][e >> 2][2 * (e & 3) + u] = (__bf16)pv;
+                }
+            };
+            // A-operand fragments are fetched TWO MFMAs ahead (fa: this step, fb: next step, loaded now: the step after), Q fragments one
+            bf16x8 fa = afrag(ic<0>{}), fb = afrag(ic<1>{}), fq = *(const bf16x8*)(qs);
+            static_for<24>([&](auto I) {                                   // steps 0..23 (up to barrier X)
+                constexpr int i = decltype(I)::value;
+                constexpr int grp = i >> 2, m = i & 3;
+                constexpr bool qk = (grp == 0 || grp == 1 || grp == 2 || grp == 4);
+                constexpr int h = (grp == 0) ? 0 : (grp == 1) ? 1 : (grp == 2) ? 2 : (grp == 3) ? 0 : (grp == 4) ? 3 : 1;
+                bf16x8 nb = fb, nq = fq;
+                if constexpr (i + 2 < 24) nb = afrag(ic<i + 2>{});
+                if constexpr (i + 1 < 24) {
+                    constexpr int g2 = (i + 1) >> 2;
+                    if constexpr (g2 == 0 || g2 == 1 || g2 == 2 || g2 == 4) nq = *(const bf16x8*)(qs + ((i + 1) & 3) * 1024);
+                }
+                if constexpr (qk) S[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fq, m == 0 ? zero : S[h], 0, 0, 0);
+                else o[m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, pf[h][m >> 1], o[m & 1], 0, 0, 0);
+                fa = fb; fb = nb; fq = nq;
+                __builtin_amdgcn_sched_barrier(0);
+                // VALU partner: groups 1,2 -> sm h0 (eighths 0-3, 4-7); 3,4 -> sm h1; 5 -> sm h2 first half
+                if constexpr (grp == 1) eighth(ic<0>{}, ic<m>{});
+                if constexpr (grp == 2) eighth(ic<0>{}, ic<4 + m>{});
+                if constexpr (grp == 3) eighth(ic<1>{}, ic<m>{});
+                if constexpr (grp == 4) eighth(ic<1>{}, ic<4 + m>{});
+                if constexpr (grp == 5) eighth(ic<2>{}, ic<m>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            // X: tile j and K(j+1) are consumed by every wave; V(j+1) (issued at the previous Y) has landed
+            drain_and_barrier();
+            if (j + 2 < nkv) { stage_k(j + 2, 0); stage_v(j + 2, 0); }
+            if (j + 3 < nkv) stage_k(j + 3, 1);
+            fa = afrag(ic<24>{}); fb = afrag(ic<25>{});
+            static_for<4>([&](auto E) { eighth(ic<2>{}, ic<4 + decltype(E)::value>{}); });
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<4>([&](auto M) {                                    // PV h2 ∥ sm h3 a
+                constexpr int m = decltype(M)::value;
+                const bf16x8 nb = afrag(ic<26 + m>{});                     // step 24+m+2 (26..29)
+                o[m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, pf[2][m >> 1], o[m & 1], 0, 0, 0);
+                fa = fb; fb = nb;
+                __builtin_amdgcn_sched_barrier(0);
+                eighth(ic<3>{}, ic<m>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            static_for<4>([&](auto E) { eighth(ic<3>{}, ic<4 + decltype(E)::value>{}); });
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<4>([&](auto M) {                                    // PV h3 (fa = step 28, fb = step 29 already in flight)
+                constexpr int m = decltype(M)::value;
+                bf16x8 nb = fb;
+                if constexpr (m < 2) nb = afrag(ic<30 + m>{});
+                o[m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, pf[3][m >> 1], o[m & 1], 0, 0, 0);
+                fa = fb; fb = nb;
+            });
+            // Y: V(j+1) consumed; K,V(j+2), K(j+3) have landed
+            drain_and_barrier();
+            if (j + 3 < nkv) stage_v(j + 3, 1);
+        }
+        l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
+    if (ILV == 2) {
+        // workgroup vote: every row of every wave bounded outright?  (max over the head's tiles of max||k||^2, then ||q||^2 of each row)
+        float* const votes = kms + FA_KMAX_SLOTS - 8;                      // the last 8 slots of the bound table (nkv <= FA_KMAX_SLOTS - 8 checked)
+        float kall = 0.f;
+        const bool can_vote = bounded && nkv <= FA_KMAX_SLOTS - 8 && nkv >= 4;
+        if (can_vote) {
+            for (int i = L.lane; i < nkv; i += 64) kall = fmaxf(kall, kms[i]);
+            kall = wave_max(kall);
+        }
+        const bool mine = can_vote && __all(qn2 * kall <= FA_SHIFT_SPAN * FA_SHIFT_SPAN) != 0;
+        block_barrier();                                                    // every wave has read its slice of kms
+        if (L.lane == 0) votes[L.wave] = mine ? 1.f : 0.f;
+        block_barrier();
+        bool all_ok = true;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) all_ok = all_ok && (votes[w] != 0.f);
+        int j = 0;
+        if (all_ok) {
+            const int npairs = (nkv - 1) / 2;                               // the last tile (ragged tail, no staging) stays with the generic tile
+            pair_loop(npairs);
+            j = 2 * npairs;
+            thr2 = FA_SHIFT_SPAN * FA_SHIFT_SPAN;                           // shift 0 stays valid for the one or two tiles left
+            if (j < nkv - 1) {                                              // K,V(j) are in place and published; the generic tile stages j+1 itself
+                tile(j, std::false_type{});
+                ++j;
+            }
+        } else {
+            // not bounded outright: the guarded one-tile paths (tile 0 refreshes, passing tiles interleaved, generic after a failure)
+            if (nkv > 1) { tile(0, std::false_type{}); j = 1; }
+            float km = (bounded && j < nkv) ? kms[j] : INFINITY;
+            for (; j < nkv - 1; ++j) {
+                if (!__all(qn2 * km <= thr2)) break;
+                km = kms[j + 1];
+                asm volatile("" : "+v"(km));
+                tile_ilv(j);
+            }
+            for (; j < nkv - 1; ++j) tile(j, std::false_type{});
+        }
+    } else if (ILV == 1) {
         // Tile 0 always refreshes.  After it, passing tiles run in the interleaved loop; the first tile that fails the guard sends
         // the wave to the generic loop for the rest of its sweep (exact as well, just not interleaved).
         int j = 0;
@@ -466,9 +617,6 @@ constexpr int FA_NB = 4;  // K/V ring depth (tile t lives in slot t & 3)
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int I> using ic = std::integral_constant<int, I>;
-template <class F, int... Is> AE_DEV void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(ic<Is>{}), ...); }
-template <int N, class F> AE_DEV void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // Timing ablations of this kernel (profiles/r01_attn_swp_ablation.json, shader cycles per KV tile for the two waves of
 // a SIMD): full 1721, without the LDS-DMA 1623, without the soft-max VALU 1203 (16 MFMAs = 2 x 512); fragment reads 2 / 4 /
@@ -695,7 +843,10 @@ extern "C" int aether_flash_attn_fwd(const void* Qh, const void* Kh, const void*
         const int rest = p.nwg - full;
         if (full > 0) {
             p.nwg = full; p.wg_first = 0;
-            if (flags & AETHER_ATTN_INTERLEAVE) {
+            if (flags & AETHER_ATTN_PAIR_PIPELINE) {
+                if (wide) hipLaunchKernelGGL((flash_attn_fwd_kernel<true, 8, 1, 2>), dim3(full), dim3(512), 0, s, p);
+                else hipLaunchKernelGGL((flash_attn_fwd_kernel<false, 8, 1, 2>), dim3(full), dim3(512), 0, s, p);
+            } else if (flags & AETHER_ATTN_INTERLEAVE) {
                 if (wide) hipLaunchKernelGGL((flash_attn_fwd_kernel<true, 8, 1, 1>), dim3(full), dim3(512), 0, s, p);
                 else hipLaunchKernelGGL((flash_attn_fwd_kernel<false, 8, 1, 1>), dim3(full), dim3(512), 0, s, p);
             } else if (wide) hipLaunchKernelGGL((flash_attn_fwd_kernel<true, 8>), dim3(full), dim3(512), 0, s, p);

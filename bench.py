@@ -385,21 +385,24 @@ def main():
             "gpu_kernel_ms_per_step_total": total_ms / args.steps,
         }
         if world == 1 and not args.no_extra_legs:
-            # The attention soft-max is exact on every path; what depends on the data is how often a tile may skip the shift
-            # refresh (include/aether_hip.h).  Two more measured legs bracket that: (a) refresh on EVERY tile
-            # (AETHER_ATTN_EXACT_MAX: the data-independent floor), (b) q/k-norm weights x3 (||q||·||k|| x9 ≈ 104 in the log2
-            # domain — beyond what round 1's whole-head gate admitted): the guard still passes after each row's first tile.
+            # The attention soft-max is exact on every path; what depends on the data is which loop a workgroup may run
+            # (include/aether_hip.h): "default" = tile-pair pipeline for workgroups bounded outright (||q||·max||k|| <= 100), guarded
+            # one-tile paths otherwise.  More measured legs bracket that: refresh on EVERY tile (AETHER_ATTN_EXACT_MAX: the
+            # data-independent floor), the one-tile interleaved and generic loops (A/B), and q/k-norm weights x3 (||q||·||k|| x9
+            # ≈ 104 in the log2 domain: NOT bounded outright, the per-tile guard still passes after each row's first tile).
             from aether_amd import _lib as L_
-            paths = {"default_guarded_shift": {"steps_per_s": steps_per_s, "attention_tflops": line["kernel_tflops"].get("attention")}}
+            paths = {"default": {"steps_per_s": steps_per_s, "attention_tflops": line["kernel_tflops"].get("attention")}}
             fl0 = model._flags
             model.set_flags(fl0 | L_.AETHER_ATTN_EXACT_MAX)
             dt, pr = timed(1, args.steps)
             paths["refresh_every_tile"] = {"steps_per_s": args.steps / dt,
                                            "attention_tflops": round(flops_per_launch("attention", B, S, D, FF) * pr["attention"][1] / (pr["attention"][0] * 1e-3) / 1e12, 1)}
-            model.set_flags(fl0 ^ L_.AETHER_ATTN_INTERLEAVE)               # the other steady-state tile variant (A/B)
-            dt, pr = timed(1, args.steps)
-            paths["interleave_toggled"] = {"interleave": not bool(fl0 & L_.AETHER_ATTN_INTERLEAVE), "steps_per_s": args.steps / dt,
-                                           "attention_tflops": round(flops_per_launch("attention", B, S, D, FF) * pr["attention"][1] / (pr["attention"][0] * 1e-3) / 1e12, 1)}
+            for name, fl in (("one_tile_interleave", (fl0 & ~L_.AETHER_ATTN_PAIR_PIPELINE) | L_.AETHER_ATTN_INTERLEAVE),
+                             ("generic_tile", fl0 & ~(L_.AETHER_ATTN_PAIR_PIPELINE | L_.AETHER_ATTN_INTERLEAVE))):      # A/B of the steady-state loops
+                model.set_flags(fl)
+                dt, pr = timed(1, args.steps)
+                paths[name] = {"steps_per_s": args.steps / dt,
+                               "attention_tflops": round(flops_per_launch("attention", B, S, D, FF) * pr["attention"][1] / (pr["attention"][0] * 1e-3) / 1e12, 1)}
             model.set_flags(fl0)
             model._weights["qn_w"].mul_(3.0); model._weights["kn_w"].mul_(3.0)
             dt, pr = timed(1, args.steps)

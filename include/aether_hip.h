@@ -110,6 +110,8 @@ int aether_qk_norm_rope(const void* qkv, int B, int S, int H, int n_text, const 
                                      of tile j is interleaved with the MFMAs of P·V(j-1) and K(j+1)·Qᵀ)                    */
 #define AETHER_ATTN_EXACT_MAX 32  /* flags bit 5: ignore kmax2: the shift is refreshed (tile maximum, rescale) on EVERY tile   */
 #define AETHER_ATTN_INTERLEAVE 256 /* flags bit 8: steady-state tiles interleave the soft-max VALU with the wave's own MFMAs     */
+#define AETHER_ATTN_PAIR_PIPELINE 512 /* flags bit 9: workgroups whose rows are all bounded outright (||q||·max||k|| <= 100 over the head)
+                                        run two tiles per iteration with each half's soft-max spread over its neighbours' MFMAs */
 #define AETHER_ATTN_TAIL_SPLIT 64 /* flags bit 6: workgroups beyond the last full round of 512 run as 128-row workgroups (2nd launch) */
 
 /* Non-causal flash attention, head_dim 64: O[b,s,h*64+d] = softmax_2(Qh·Khᵀ)·V where softmax_2 uses base 2, i.e.

@@ -254,7 +254,7 @@ def test_qk_norm_rope(cuda, hip_lib, B, H, S, n_text):
 
 # attention kernel variants: lock-step (narrow / wide store), lock-step with the tail split (64: with <= 512 workgroups
 # everything then runs as 128-row workgroups), software-pipelined (narrow / wide store)
-ATTN_FLAGS = [0, 1, 64 | 1, 16, 16 | 1, 256, 256 | 1]   # 256: in-wave interleaved steady-state tiles
+ATTN_FLAGS = [0, 1, 64 | 1, 16, 16 | 1, 256, 256 | 1, 512, 512 | 1]   # 256: in-wave interleaved steady-state tiles; 512: tile-pair pipeline
 
 
 def _attn_case(B, H, S, seed, q_gain=1.0):
@@ -337,7 +337,7 @@ def test_flash_attention_bound_gate(cuda, hip_lib, flags):
 
 
 @pytest.mark.parametrize("pattern", ["hot_rows", "late_hot_keys", "early_peak", "cold_start", "span_edge"])
-@pytest.mark.parametrize("flags", [0, 1, 256, 257])
+@pytest.mark.parametrize("flags", [0, 1, 256, 257, 513])
 def test_flash_attention_guarded_shift(cuda, hip_lib, flags, pattern):
     """The lock-step kernel's soft-max keeps a per-row shift m (a true score maximum of the tiles it was refreshed on) and
     exponentiates a tile against the un-refreshed m whenever ||q||·max_tile||k|| <= m + 90 proves exp2 cannot overflow; any

@@ -179,7 +179,7 @@ struct Plan {
         const size_t off = top;
         top = align_up(top + bytes, 256);
         if (top > peak) peak = top;
-        return dry ? (char*)nullptr + 256 + off : arena + off;   // dry: a non-null dummy, never dereferenced
+        return dry ? reinterpret_cast<char*>((uintptr_t)256 + off) : arena + off;   // dry: a non-null dummy, never dereferenced
     }
     bool fail(int code, const std::string& m) { if (!rc) { rc = code; err = m; } return false; }
     bool ok(int r, const char* what) { if (r != 0 && !rc) { rc = r; err = what; } return rc == 0; }
@@ -200,9 +200,9 @@ struct Plan {
         const Shape5 key(NB, T, H, W, C);
         const size_t bytes = align_up((size_t)NB * T * H * W * C * 2, 256);
         if (dry) {
-            if (h->pool.count(key) || dry_pool.count(key)) return (char*)nullptr + 256;
+            if (h->pool.count(key) || dry_pool.count(key)) return reinterpret_cast<char*>((uintptr_t)256);
             dry_pool[key] = pool_need; pool_need += bytes;
-            return (char*)nullptr + 256;
+            return reinterpret_cast<char*>((uintptr_t)256);
         }
         auto it = h->pool.find(key);
         if (it == h->pool.end()) {
@@ -220,7 +220,7 @@ struct Plan {
         const size_t bytes = align_up((size_t)n * 4, 256);
         if (dry) {
             if (!h->taps.count(key) && !dry_taps.count(key)) { dry_taps[key] = pool_need; pool_need += bytes; }
-            return (const int*)((char*)nullptr + 256);
+            return reinterpret_cast<const int*>((uintptr_t)256);
         }
         auto it = h->taps.find(key);
         if (it == h->taps.end()) {

@@ -2,7 +2,9 @@
 /root/reference/aether/pipelines/aetherv1_pipeline_cogvideox.py:690-965 (`__call__`) and P:514-688 (`prepare_latents`),
 for inputs that are ALREADY preprocessed tensors.  One function, no helpers, every statement in reference order, so
 the (re-structured) product pipeline can be compared with it output-for-output on the same modules and seed.
-PARITY UNPINNED (see oracle/__init__.py)."""
+The orchestration it restates IS pinned: the product pipeline, which equals this restatement bit for bit (tests/test_pipeline_cpu.py),
+also equals the reference's own pipeline class executed against a stub diffusers (tests/test_reference_pins_cpu.py).  The three modules
+it drives (oracle/dit.py, oracle/vae.py, the scheduler) remain PARITY UNPINNED (see oracle/__init__.py)."""
 from __future__ import annotations
 
 import math

@@ -1,4 +1,6 @@
 """ORACLE (test infrastructure only): 3-D rotary tables exactly as the reference builds them.
+PINNED: equal to the outputs of the reference's own get_3d_rotary_pos_embed / get_resize_crop_region_for_grid (P:25-163) on the
+fixtures of tests/golden/pipeline.npz (tests/test_reference_pins_cpu.py), given the published formula of diffusers' get_1d_rotary_pos_embed.
 
 Follows /root/reference/aether/pipelines/aetherv1_pipeline_cogvideox.py:25-144 (`get_3d_rotary_pos_embed`,
 whose only change w.r.t. diffusers is `fps_factor` scaling the temporal positions, P:35,81-90), P:148-163

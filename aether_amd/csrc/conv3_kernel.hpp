@@ -210,6 +210,29 @@ __global__ __launch_bounds__(512) void conv3_gemm_kernel(GemmArgs p) {
 
     // ---- epilogue: rows of the padded enumeration -> compact [NB, oT, oH, oW, Cout]; padding rows are dropped ----------------
     // acc[mt][nt][r] = C[m][n], m = m0 + (wm*MT + mt)*32 + l32,  n = n0 + (wn*NT + nt)*32 + 8*(r>>2) + 4*hi + (r&3)
+    // operands fetched in batches before use (see gemm_kernel.hpp): the bias of the wave's column groups once, the residual rows of a
+    // 32-row block together
+    const bool has_bias = p.bias != nullptr;
+    const bool has_res = (EPI == EPI_BIAS_GATE_RES) && p.R != nullptr;
+    int ncol[NT];
+    bool n_ok[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int nbase = n0 + (wn * NT + nt) * 32;
+        n_ok[nt] = nbase < p.N;
+        ncol[nt] = n_ok[nt] ? nbase : 0;
+    }
+    f32x4 bv[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bv[nt][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (has_bias) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bv[nt][g] = *(const f32x4*)(p.bias + ncol[nt] + 8 * g + 4 * hi);
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int m = m0 + (wm * MT + mt) * 32 + l32;
@@ -217,27 +240,27 @@ __global__ __launch_bounds__(512) void conv3_gemm_kernel(GemmArgs p) {
         const int hp = rr / p.iW, wp = rr - hp * p.iW;
         const bool m_ok = (m < p.M) && (hp < p.oH) && (wp < p.oW);
         const size_t orow = ((size_t)f * p.oH + hp) * p.oW + wp;
+        u16x4 rv[NT][4];
+        if (has_res) {
+            const size_t rrow = m_ok ? orow : 0;          // rows dropped by the padded enumeration read row 0 and are not stored
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) rv[nt][g] = *(const u16x4*)(p.R + rrow * p.ldr + ncol[nt] + 8 * g + 4 * hi);
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int nbase = n0 + (wn * NT + nt) * 32;
-            if (nbase >= p.N) continue;                   // wave-uniform
+            if (!n_ok[nt]) continue;                      // wave-uniform
+            const int nbase = ncol[nt];
             unsigned pk[4][2];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int n = nbase + 8 * g + 4 * hi;
                 float v[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = acc[mt][nt][4 * g + c];
-                if (p.bias != nullptr) {
-                    const f32x4 bv = *(const f32x4*)(p.bias + n);
+                for (int c = 0; c < 4; ++c) v[c] = acc[mt][nt][4 * g + c] + bv[nt][g][c];
+                if (has_res) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] += bv[c];
-                }
-                if (EPI == EPI_BIAS_GATE_RES && p.R != nullptr) {
-                    u16x4 rv = {0, 0, 0, 0};
-                    if (m_ok) rv = *(const u16x4*)(p.R + orow * p.ldr + n);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] += bf16_bits_to_f32(rv[c]);
+                    for (int c = 0; c < 4; ++c) v[c] += bf16_bits_to_f32(rv[nt][g][c]);
                 }
                 pk[g][0] = pack_bf16x2(v[0], v[1]);
                 pk[g][1] = pack_bf16x2(v[2], v[3]);

@@ -17,6 +17,7 @@ AETHER_EPI_BIAS_GATE_RES = 2
 AETHER_GEMM_WIDE_STORE = 1
 AETHER_GEMM_PINGPONG = 4      # ping-pong main loop (see include/aether_hip.h)
 AETHER_GEMM_PINGPONG2 = 8
+AETHER_GEMM_4WAVE = 1024      # four-wave main loop (one wave per SIMD, in-wave interleaving)
 AETHER_ATTN_PIPELINED = 16    # attention: software-pipelined kernel
 AETHER_ATTN_EXACT_MAX = 32    # attention: ignore the score bound, always run the exact online soft-max
 AETHER_ATTN_TAIL_SPLIT = 64   # attention: the partly filled last round runs as 128-row workgroups (second launch)

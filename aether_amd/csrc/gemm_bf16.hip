@@ -4,7 +4,7 @@
 // transformer call (aether/pipelines/aetherv1_pipeline_cogvideox.py:865-875): to_q/to_k/to_v, to_out,
 // ff.net.0.proj (+GELU-tanh), ff.net.2 (+gate·x+residual), patch_embed.proj/text_proj, proj_out.
 // Kernel: gemm_kernel.hpp, 256x256x64 tile (2x4 waves, 128x64 per wave).
-#include "gemm_kernel.hpp"
+#include "gemm4_kernel.hpp"
 #include "../../include/aether_hip.h"
 
 using namespace aether;
@@ -112,10 +112,14 @@ extern "C" int aether_gemm_bf16(const void* A, int lda, const void* W, int ldw, 
         (size_t)ks * rest * 256 * 256 * sizeof(float) > splitk_ws_bytes)
         ks = 1;
     p.ntile_launch = (ks > 1) ? full : tiles;
+    const bool four_wave = (flags & AETHER_GEMM_4WAVE) != 0;
 #define LAUNCH(E)                                                                                                        \
     do {                                                                                                                 \
         dim3 grid(p.ntile_launch * p.ksplit);                                                                            \
-        if (wide) hipLaunchKernelGGL((gemm_bf16_kernel<2, 4, 4, 2, E, true, false>), grid, block, 0, s, p);               \
+        if (four_wave && p.ksplit == 1) {                                                                                \
+            if (wide) hipLaunchKernelGGL((gemm4_bf16_kernel<E, true>), grid, dim3(256), 0, s, p);                         \
+            else hipLaunchKernelGGL((gemm4_bf16_kernel<E, false>), grid, dim3(256), 0, s, p);                             \
+        } else if (wide) hipLaunchKernelGGL((gemm_bf16_kernel<2, 4, 4, 2, E, true, false>), grid, block, 0, s, p);        \
         else hipLaunchKernelGGL((gemm_bf16_kernel<2, 4, 4, 2, E, false, false>), grid, block, 0, s, p);                   \
     } while (0)
 #define LAUNCH_EPI()                                        \

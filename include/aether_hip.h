@@ -50,6 +50,9 @@ int aether_check_device(void);
                                       "read fragments from LDS" and "issue MFMAs" slots, phase-locked by s_barrier, LDS-DMA
                                       issued in the MFMA shadow (+8..12 % over the lock-step loop on MI355X)              */
 #define AETHER_GEMM_PINGPONG2 8     /* flags bit 3 (instead of bit 2): same with two k-steps per slot                     */
+#define AETHER_GEMM_4WAVE 1024      /* flags bit 10: four-wave main loop (one wave per SIMD, 128x128 register tile each, LDS reads and
+                                      LDS-DMA issued between the wave's own MFMAs, one barrier per K tile); full rounds only, the
+                                      split-K tail launch keeps the eight-wave kernel                                          */
 
 /* C[M,N] = epi(A[M,K] · W[N,K]ᵀ), bf16 in / bf16 out / fp32 accumulate on MFMA.
  * Replaces nn.Linear in CogVideoXBlock / CogVideoXPatchEmbed / proj_out under P:865-875

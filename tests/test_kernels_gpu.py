@@ -28,7 +28,7 @@ def _bf16_close(got, ref_fp32, what, rel=6e-3, max_ulp_frac=2.0):
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 256), (300, 256, 128), (1000, 512, 3072), (226, 512, 4096), (37, 224, 512)])
-@pytest.mark.parametrize("flags", [0, 1, 1 | 4, 1 | 8, 4, 1 | 12])     # bit 0: 16-byte stores; bits 2/3: ping-pong main loop (1 / 2 k-steps per slot; both: fragment reads in the compute slots)
+@pytest.mark.parametrize("flags", [0, 1, 1 | 4, 1 | 8, 4, 1 | 12, 1024, 1025])     # bit 0: 16-byte stores; bits 2/3: ping-pong main loop (1 / 2 k-steps per slot; both: fragment reads in the compute slots); bit 10: four-wave loop
 def test_gemm_bias(cuda, hip_lib, M, N, K, flags):
     from aether_amd import ops
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
@@ -52,7 +52,7 @@ def test_gemm_transpose_detecting(cuda, hip_lib):
     assert torch.equal(out.cpu().float(), W.float().t())
 
 
-@pytest.mark.parametrize("flags", [0, 5, 13])
+@pytest.mark.parametrize("flags", [0, 5, 13, 1025])
 def test_gemm_gelu(cuda, hip_lib, flags):
     from aether_amd import ops
     g = torch.Generator().manual_seed(5)
@@ -66,7 +66,7 @@ def test_gemm_gelu(cuda, hip_lib, flags):
     _bf16_close(out, ref, "gemm+gelu")
 
 
-@pytest.mark.parametrize("flags", [0, 5, 9, 13])
+@pytest.mark.parametrize("flags", [0, 5, 9, 13, 1024, 1025])
 def test_gemm_gate_residual_inplace(cuda, hip_lib, flags):
     from aether_amd import ops
     g = torch.Generator().manual_seed(6)
@@ -91,7 +91,7 @@ def test_gemm_gate_residual_inplace(cuda, hip_lib, flags):
     _bf16_close(x, ref, "gemm+gate+res")
 
 
-@pytest.mark.parametrize("gflags", [5, 9, 13])
+@pytest.mark.parametrize("gflags", [5, 9, 13, 1029])
 @pytest.mark.parametrize("epi", ["bias", "gelu", "gate_res"])
 def test_gemm_tail_split_k(cuda, hip_lib, epi, gflags):
     """17 x 16 = 272 tiles = one full round of 256 + 16: with scratch the 16 tail tiles run as a second launch whose K loop

@@ -1,0 +1,106 @@
+// Measurement only: what a bare stream of bf16 MFMAs reaches on every CU at once under the board's power cap, by instruction shape —
+// v_mfma_f32_32x32x16_bf16 (what our kernels issue) against v_mfma_f32_16x16x32_bf16 (what the vendor GEMM issues) — with a 128x128
+// register tile per wave, operands alternating between two random fragment sets per k-step (fresh data on the operand buses as in
+// a real K loop), one or two waves per SIMD.  Driven by tools/gpu_mfma_power_probe.py.
+#include <hip/hip_runtime.h>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int SHAPE>
+__global__ __launch_bounds__(SHAPE == 2 ? 512 : 256) void mfma_probe(const bf16x8* __restrict__ src, int iters, float* __restrict__ out, float* __restrict__ sink) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+    float keep = 0.f;
+    if (SHAPE == 0) {                       // 32x32x16, 4x4 accumulator tiles (128x128 per wave): 16 MFMAs per k-step of 16
+        bf16x8 a[2][4], b[2][4];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[s][i] = src[(s * 8 + i) * 64 + lane]; b[s][i] = src[(s * 8 + 4 + i) * 64 + lane]; }
+        f32x16 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) keep += acc[i][j][0] + acc[i][j][7];
+    } else if (SHAPE == 1) {                // 16x16x32, 8x8 accumulator tiles (128x128 per wave): 64 MFMAs per k-step of 32
+        bf16x8 a[2][8], b[2][8];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { a[s][i] = src[(s * 16 + i) * 64 + lane]; b[s][i] = src[(s * 16 + 8 + i) * 64 + lane]; }
+        f32x4 acc[8][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) keep += acc[i][j][0] + acc[i][j][3];
+    } else {                                // 32x32x16 on a 128x64 tile (8 accumulator tiles, 128 registers): the two-waves-per-SIMD form
+        bf16x8 a[2][4], b[2][2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[s][i] = src[(s * 8 + i) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) b[s][i] = src[(s * 8 + 4 + i) * 64 + lane];
+        }
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) keep += acc[i][j][0] + acc[i][j][7];
+    }
+    if (keep == 1.2345f) sink[0] = keep;
+    if (threadIdx.x == 0 && blockIdx.x < 256) {
+        out[2 * blockIdx.x] = (float)(__builtin_readcyclecounter() - c0);
+        out[2 * blockIdx.x + 1] = (float)(wall_clock64() - r0);
+    }
+}
+
+extern "C" int run_mfma_probe(int shape, int nwaves, const void* src, int iters, float* out, float* sink, int nblocks, void* stream) {
+    dim3 grid(nblocks), block(nwaves * 64);
+    hipStream_t s = (hipStream_t)stream;
+    if (shape == 0) hipLaunchKernelGGL((mfma_probe<0>), grid, block, 0, s, (const bf16x8*)src, iters, out, sink);
+    else if (shape == 1) hipLaunchKernelGGL((mfma_probe<1>), grid, block, 0, s, (const bf16x8*)src, iters, out, sink);
+    else hipLaunchKernelGGL((mfma_probe<2>), grid, block, 0, s, (const bf16x8*)src, iters, out, sink);
+    return (int)hipGetLastError();
+}

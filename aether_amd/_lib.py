@@ -65,6 +65,7 @@ SIGNATURES = {
     "aether_groupnorm_stats": (_i, [_vp, _i, _i, _i, _i, _f, _fp, _fp, _fp, _i, _fp, _fp, _vp]),
     "aether_spatial_cond": (_i, [_vp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _vp]),
     "aether_groupnorm_apply": (_i, [_vp, _i, _i, _i, _i, _i, _fp, _i, _vp, _i, _i, _i, _i, _i, _i, _fp, _i, _i, _i, C.POINTER(C.c_int), _vp]),
+    "aether_groupnorm_apply_causal": (_i, [_vp, _i, _i, _i, _i, _i, _fp, _i, _vp, _i, _i, _i, _i, _fp, _i, _i, _i, C.POINTER(C.c_int), _vp, _vp, _vp]),
     "aether_causal_front": (_i, [_vp, _i, _i, C.c_long, _vp, _vp, _vp]),
     "aether_resample_pad": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "aether_preprocess_frames": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -148,6 +148,12 @@ struct GnApplyArgs {
     const float* cond; int zT, zH, zW;                    // [NB, zT, zH, zW, 2, C] or null
     int tmap[16];                                         // source latent frame of output frame t
     int rh, log2_cw;                                      // H / zH, log2((W / zW) / RW): runs per latent voxel
+    // causal front fused into the store (pt == 2): frames 0, 1 of y = the previous chunk's last two padded frames (front_prev) or,
+    // on the first chunk, copies of the first frame; the last two frames of y are saved for the next chunk (front_next).  Both
+    // caches are [NB, 2, oH, oW, C] like y's frames; only interiors are read or written (y's border is zero and stays zero).
+    int causal;
+    const unsigned short* front_prev;
+    unsigned short* front_next;
 };
 
 // One workgroup per (t, h) row of one batch item.  A thread owns one channel octet (256 % (C/8) == 0, so the octet of item
@@ -163,6 +169,10 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(GnApplyArgs p) {
     const int units = (p.W / RW) << p.log2_opv;
     const unsigned short* xrow = p.x + ((((size_t)nb * p.T + t) * p.H + h) * p.W) * p.C;
     unsigned short* yrow = p.y + ((((size_t)nb * p.oT + t + p.pt) * p.oH + h + p.ph) * p.oW + p.pw) * p.C;
+    const size_t plane = (size_t)p.oH * p.oW * p.C;                  // elements of one padded frame
+    const size_t row_in_plane = ((size_t)(h + p.ph) * p.oW + p.pw) * p.C;
+    // row h of saved frame 0 for THIS batch item (saved frame k = frame T - 2 + k of the chunk; k = 1 is `plane` further)
+    unsigned short* nrow = p.causal ? p.front_next + (size_t)nb * 2 * plane + row_in_plane : nullptr;
     const int c0 = (threadIdx.x & (opv - 1)) << 3;
     const float* aff = p.affine + (size_t)nb * 2 * p.C + c0;
     const f32x4 s0 = *(const f32x4*)(aff), s1 = *(const f32x4*)(aff + 4);
@@ -197,8 +207,27 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(GnApplyArgs p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = silu(o[e]);
             }
-            *(uint4*)(yrow + off + (size_t)k * p.C) =
-                make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+            const uint4 ov = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+            *(uint4*)(yrow + off + (size_t)k * p.C) = ov;
+            if (p.causal) {
+                const size_t vo = off + (size_t)k * p.C;
+                if (t == 0 && p.front_prev == nullptr) {             // first chunk: the two front frames replicate frame 0
+                    *(uint4*)(yrow - 2 * plane + vo) = ov;
+                    *(uint4*)(yrow - plane + vo) = ov;
+                    if (p.T == 1) *(uint4*)(nrow + vo) = ov;          // one-frame chunk: the saved pair is (front frame 1, frame 0)
+                }
+                if (t >= p.T - 2) *(uint4*)(nrow + (size_t)(t - (p.T - 2)) * plane + vo) = ov;
+            }
+        }
+    }
+    if (p.causal && t == 0 && p.front_prev != nullptr) {             // later chunks: front frames = the saved pair, row by row
+        const unsigned short* prow = p.front_prev + (size_t)nb * 2 * plane + row_in_plane;
+        const int vecs = p.W << p.log2_opv;
+        for (int u = threadIdx.x; u < vecs; u += 256) {
+            const uint4 a = *(const uint4*)(prow + (size_t)u * 8), b = *(const uint4*)(prow + plane + (size_t)u * 8);
+            *(uint4*)(yrow - 2 * plane + (size_t)u * 8) = a;
+            *(uint4*)(yrow - plane + (size_t)u * 8) = b;
+            if (p.T == 1) *(uint4*)(nrow + (size_t)u * 8) = b;       // one-frame chunk: saved pair = (front frame 1, frame 0)
         }
     }
 }
@@ -240,10 +269,12 @@ extern "C" int aether_spatial_cond(const void* zq, int NB, int zV, int zC, int C
     return aether_check_launch("spatial_cond");
 }
 
-extern "C" int aether_groupnorm_apply(const void* x, int NB, int T, int H, int W, int C, const float* affine, int silu_flag, void* y,
-                                      int oT, int oH, int oW, int pt, int ph, int pw, const float* cond, int zT, int zH, int zW,
-                                      const int* tmap_host, void* stream) {
+static int groupnorm_apply_impl(const void* x, int NB, int T, int H, int W, int C, const float* affine, int silu_flag, void* y, int oT, int oH,
+                                int oW, int pt, int ph, int pw, const float* cond, int zT, int zH, int zW, const int* tmap_host, int causal,
+                                const void* front_prev, void* front_next, void* stream) {
     if (!x || !y || !affine) return aether_set_error(AETHER_ERR_ARG, "groupnorm_apply: null pointer");
+    if (causal && (pt != 2 || oT != T + 2 || !front_next || (((uintptr_t)front_prev | (uintptr_t)front_next) & 15)))
+        return aether_set_error(AETHER_ERR_ARG, "groupnorm_apply_causal: needs pt == 2, oT == T + 2 and a 16-byte aligned cache for the next chunk");
     const int l2 = ilog2_exact(C / 8);
     if (C % 8 != 0 || l2 < 0 || l2 > 8) return aether_set_error(AETHER_ERR_SHAPE, "groupnorm_apply: C/8 must be a power of two <= 256");
     int rw = 1;
@@ -252,6 +283,7 @@ extern "C" int aether_groupnorm_apply(const void* x, int NB, int T, int H, int W
     p.x = (const unsigned short*)x; p.T = T; p.H = H; p.W = W; p.C = C; p.log2_opv = l2;
     p.affine = affine;
     p.y = (unsigned short*)y; p.oT = oT; p.oH = oH; p.oW = oW; p.pt = pt; p.ph = ph; p.pw = pw; p.silu = silu_flag;
+    p.causal = causal; p.front_prev = (const unsigned short*)front_prev; p.front_next = (unsigned short*)front_next;
     if (cond != nullptr) {
         if (!tmap_host || T > 16 || zT <= 0 || zH <= 0 || zW <= 0 || H % zH || W % zW) return aether_set_error(AETHER_ERR_SHAPE, "groupnorm_apply: unsupported latent volume");
         const int lrw = ilog2_exact(W / zW);
@@ -274,4 +306,18 @@ extern "C" int aether_groupnorm_apply(const void* x, int NB, int T, int H, int W
         default: hipLaunchKernelGGL(groupnorm_apply_kernel<1>, grid, block, 0, AE_STREAM, p); break;
     }
     return aether_check_launch("groupnorm_apply");
+}
+
+extern "C" int aether_groupnorm_apply(const void* x, int NB, int T, int H, int W, int C, const float* affine, int silu_flag, void* y,
+                                      int oT, int oH, int oW, int pt, int ph, int pw, const float* cond, int zT, int zH, int zW,
+                                      const int* tmap_host, void* stream) {
+    return groupnorm_apply_impl(x, NB, T, H, W, C, affine, silu_flag, y, oT, oH, oW, pt, ph, pw, cond, zT, zH, zW, tmap_host, 0, nullptr, nullptr,
+                                stream);
+}
+
+extern "C" int aether_groupnorm_apply_causal(const void* x, int NB, int T, int H, int W, int C, const float* affine, int silu_flag, void* y,
+                                             int oH, int oW, int ph, int pw, const float* cond, int zT, int zH, int zW, const int* tmap_host,
+                                             const void* front_prev, void* front_next, void* stream) {
+    return groupnorm_apply_impl(x, NB, T, H, W, C, affine, silu_flag, y, T + 2, oH, oW, 2, ph, pw, cond, zT, zH, zW, tmap_host, 1, front_prev,
+                                front_next, stream);
 }

@@ -257,7 +257,10 @@ struct Plan {
         return out;
     }
     // GroupNorm (+SpatialNorm3D) + SiLU of x into a zero-bordered volume [NB, T+pad_t, H+2p, W+2p, C]
-    char* norm_to_padded(const Act& x, const NormW& nw, int pad_t, int pad_hw, const Act* zq, float eps) {
+    // front_next != nullptr: the causal front (frames 0, 1 from front_prev or copies of frame 0; last two frames saved to front_next) is
+    // written by the same launch (aether_groupnorm_apply_causal)
+    char* norm_to_padded(const Act& x, const NormW& nw, int pad_t, int pad_hw, const Act* zq, float eps, const char* front_prev = nullptr,
+                         char* front_next = nullptr) {
         const int G = h->cfg.norm_num_groups, V = x.T * x.H * x.W;
         const int nblk = std::max(1, std::min(256, (V + 127) / 128));
         float* part = (float*)alloc((size_t)x.NB * nblk * 2 * x.C * 4);
@@ -275,8 +278,15 @@ struct Plan {
             int tmap[64];
             if (x.T > 64) { fail(AETHER_ERR_SHAPE, "vae: more than 64 frames in one chunk"); return vol; }
             nearest_time_map(x.T, zq->T, tmap);
-            ok(aether_groupnorm_apply(x.p, x.NB, x.T, x.H, x.W, x.C, affine, 1, vol, x.T + pad_t, x.H + 2 * pad_hw, x.W + 2 * pad_hw, pad_t, pad_hw,
-                                      pad_hw, cond, zq->T, zq->H, zq->W, tmap, stream), "aether_groupnorm_apply");
+            if (front_next)
+                ok(aether_groupnorm_apply_causal(x.p, x.NB, x.T, x.H, x.W, x.C, affine, 1, vol, x.H + 2 * pad_hw, x.W + 2 * pad_hw, pad_hw, pad_hw, cond,
+                                                 zq->T, zq->H, zq->W, tmap, front_prev, front_next, stream), "aether_groupnorm_apply_causal");
+            else
+                ok(aether_groupnorm_apply(x.p, x.NB, x.T, x.H, x.W, x.C, affine, 1, vol, x.T + pad_t, x.H + 2 * pad_hw, x.W + 2 * pad_hw, pad_t, pad_hw,
+                                          pad_hw, cond, zq->T, zq->H, zq->W, tmap, stream), "aether_groupnorm_apply");
+        } else if (front_next) {
+            ok(aether_groupnorm_apply_causal(x.p, x.NB, x.T, x.H, x.W, x.C, affine, 1, vol, x.H + 2 * pad_hw, x.W + 2 * pad_hw, pad_hw, pad_hw, nullptr, 0,
+                                             0, 0, nullptr, front_prev, front_next, stream), "aether_groupnorm_apply_causal");
         } else {
             ok(aether_groupnorm_apply(x.p, x.NB, x.T, x.H, x.W, x.C, affine, 1, vol, x.T + pad_t, x.H + 2 * pad_hw, x.W + 2 * pad_hw, pad_t, pad_hw,
                                       pad_hw, nullptr, 0, 0, 0, nullptr, stream), "aether_groupnorm_apply");
@@ -303,16 +313,13 @@ struct Plan {
     std::map<std::string, Cache>* caches = nullptr;
     size_t cache_bytes_hint = 0;
 
-    void causal_front(char* vol, int NB, int Tp, int Hp, int Wp, int C, const std::string& key) {
+    // the two cache buffers of a conv for this chunk: prev (null on the first chunk) and next; advances the cache
+    void causal_buffers(const std::string& key, const char** prev, char** next) {
         Cache& c = (*caches)[key];
-        const size_t bytes = (size_t)NB * 2 * Hp * Wp * C * 2;
-        if (c.buf[0] == nullptr) { fail(AETHER_ERR_ARG, "vae: internal: cache not reserved for " + key); return; }
-        (void)bytes;
-        const char* prev = c.filled ? c.buf[(c.filled - 1) & 1] : nullptr;
-        char* next = c.buf[c.filled & 1];
+        if (c.buf[0] == nullptr) { fail(AETHER_ERR_ARG, "vae: internal: cache not reserved for " + key); *prev = nullptr; *next = nullptr; return; }
+        *prev = c.filled ? c.buf[(c.filled - 1) & 1] : nullptr;
+        *next = c.buf[c.filled & 1];
         c.filled++;
-        if (dry || rc) return;
-        ok(aether_causal_front(vol, NB, Tp, (long)Hp * Wp * C, prev, next, stream), "aether_causal_front");
     }
     // caches are reserved (arena, group lifetime) by a dry walk of the first chunk: reserve_mode records the keys and sizes
     bool reserve_mode = false;
@@ -320,9 +327,13 @@ struct Plan {
 
     Act causal_conv(const Act& x, const NormW& nw, const ConvW& cw, const std::string& key, const Act* zq, const char* residual, float eps,
                     char* dst = nullptr) {
-        char* vol = norm_to_padded(x, nw, 2, 1, zq, eps);
+        // GroupNorm + SiLU into the padded volume; the same launch writes the causal front (previous chunk's last two frames, or
+        // copies of the first frame) and saves this chunk's last two frames for the next one
+        const char* prev = nullptr;
+        char* next = nullptr;
         if (reserve_mode) reserve_list.emplace_back(key, (size_t)x.NB * 2 * (x.H + 2) * (x.W + 2) * x.C * 2);
-        else causal_front(vol, x.NB, x.T + 2, x.H + 2, x.W + 2, x.C, key);
+        else causal_buffers(key, &prev, &next);
+        char* vol = norm_to_padded(x, nw, 2, 1, zq, eps, prev, next);
         return conv_gemm(vol, x.NB, x.T + 2, x.H + 2, x.W + 2, x.C, cw, x.T, x.H, x.W, 1, residual, dst);
     }
     Act resnet(const Act& x, const std::string& prefix, const Act* zq) {

@@ -463,8 +463,10 @@ class AetherVAE:
         _lib.check(rc, "aether_gemm_bf16")
         return out
 
-    def _norm_to_padded(self, x: torch.Tensor, norm: _Norm, pad_t: int, pad_hw: int, silu: bool, zq=None, eps=None) -> torch.Tensor:
-        """GroupNorm (+SpatialNorm3D) + SiLU of x [NB,T,H,W,C] into a zero-bordered volume [NB,T+pad_t,H+2p,W+2p,C]."""
+    def _norm_to_padded(self, x: torch.Tensor, norm: _Norm, pad_t: int, pad_hw: int, silu: bool, zq=None, eps=None, causal=None) -> torch.Tensor:
+        """GroupNorm (+SpatialNorm3D) + SiLU of x [NB,T,H,W,C] into a zero-bordered volume [NB,T+pad_t,H+2p,W+2p,C].
+        causal = (cache dict, key): the same launch also writes the two causal front frames (from cache[key] or copies of frame 0)
+        and stores the chunk's last two frames back as cache[key] (aether_groupnorm_apply_causal; what the C launch plan uses)."""
         NB, T, H, W, Cc = x.shape
         G = self.config.norm_num_groups
         V = T * H * W
@@ -477,6 +479,7 @@ class AetherVAE:
                                                     part.data_ptr(), nblk, stats.data_ptr(), affine.data_ptr(), self._stream()),
                    "aether_groupnorm_stats")
         vol = self._padded((NB, T + pad_t, H + 2 * pad_hw, W + 2 * pad_hw, Cc))
+        cond, tmap, zT, zH, zW = None, None, 0, 0, 0
         if norm.spatial:
             _, zT, zH, zW, zC = zq.shape
             cond = torch.empty(NB * zT * zH * zW * 2 * Cc, dtype=torch.float32, device=self.device)
@@ -484,6 +487,17 @@ class AetherVAE:
                                                      norm.wb.data_ptr(), norm.bb.data_ptr(), cond.data_ptr(), self._stream()),
                        "aether_spatial_cond")
             tmap = (C.c_int * T)(*_nearest_time_map(T, zT))
+        if causal is not None:
+            cache, key = causal
+            assert pad_t == 2
+            prev = cache.get(key)
+            nxt = torch.empty((NB, 2) + tuple(vol.shape[2:]), dtype=vol.dtype, device=vol.device)
+            _lib.check(self._lib.aether_groupnorm_apply_causal(x.data_ptr(), NB, T, H, W, Cc, affine.data_ptr(), int(silu), vol.data_ptr(), vol.shape[2],
+                                                               vol.shape[3], pad_hw, pad_hw, _lib.ptr(cond), zT, zH, zW, tmap, _lib.ptr(prev),
+                                                               nxt.data_ptr(), self._stream()), "aether_groupnorm_apply_causal")
+            cache[key] = nxt
+            return vol
+        if norm.spatial:
             rc = self._lib.aether_groupnorm_apply(x.data_ptr(), NB, T, H, W, Cc, affine.data_ptr(), int(silu), vol.data_ptr(), vol.shape[1],
                                                   vol.shape[2], vol.shape[3], pad_t, pad_hw, pad_hw, cond.data_ptr(), zT, zH, zW, tmap,
                                                   self._stream())

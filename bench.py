@@ -119,6 +119,32 @@ def cpu_baseline_vae():
             "sample": f"fp32 torch-CPU oracle: one 8x240x360 encoder tile-chunk ({te:.1f} s) x 46.1, one 2x30x45 decoder tile-chunk ({td:.1f} s) x 49.5"}
 
 
+def mfma_power_cap_leg():
+    """What a bare stream of v_mfma_f32_32x32x16_bf16 reaches on THIS box under its power cap (tools/probes/mfma_power_probe.hip,
+    built by __graft_entry__.build(); 2 x 25 ms): random operands like the bench's data, and all-zero operands (the datasheet peak
+    `roofline.peak` is priced against).  Context for `roofline.frac`, not a replacement for it; None if the probe is not built."""
+    import ctypes
+    so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "probes", "mfma_power_probe.so")
+    if not os.path.exists(so):
+        return None
+    lib = ctypes.CDLL(so)
+    lib.run_mfma_probe.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    out = torch.zeros(1024, dtype=torch.float32, device=dev)
+    sink = torch.zeros(4, dtype=torch.float32, device=dev)
+    res = {"kernel": "bare v_mfma_f32_32x32x16_bf16 stream, 128x128 register tile, one wave per SIMD, every CU", "source": "tools/probes/mfma_power_probe.hip"}
+    iters = 40000
+    for name, data in (("random_operands", torch.randn(32 * 64 * 8, device=dev).bfloat16()), ("zero_operands", torch.zeros(32 * 64 * 8, device=dev).bfloat16())):
+        for _ in range(2):
+            if lib.run_mfma_probe(0, 4, data.data_ptr(), iters, out.data_ptr(), sink.data_ptr(), 256, None) != 0:
+                return None
+            torch.cuda.synchronize()
+        t = out[:512].view(256, 2).double().cpu()
+        cyc, ns = float(t[:, 0].median()), float(t[:, 1].median()) * 10.0
+        res[name] = {"tflops": round(256 * 4 * iters * 32 * 32768 / ns / 1e3, 1), "clock_ghz": round(cyc / ns, 3)}
+    return res
+
+
 def vae_leg(dev, reps=3):
     """VAE encode of a 41x480x720 clip and decode of its 11x60x90 latent exactly as the pipeline calls them (tiling + slicing on):
     seconds (HIP events on the launch stream), algorithmic TFLOP with the reference's tiling (175 / 369) and the
@@ -410,6 +436,12 @@ def main():
                                         "attention_tflops": round(flops_per_launch("attention", B, S, D, FF) * pr["attention"][1] / (pr["attention"][0] * 1e-3) / 1e12, 1)}
             model._weights["qn_w"].div_(3.0); model._weights["kn_w"].div_(3.0)
             line["attention_paths"] = paths
+        if world == 1 and not args.no_extra_legs:
+            cap = mfma_power_cap_leg()
+            if cap is not None:
+                cap["whole_step_frac_of_random_operand_stream"] = round(steps_per_s * B * 260.8 / cap["random_operands"]["tflops"], 4)
+                cap["dominant_kernel_frac_of_random_operand_stream"] = round(ach / cap["random_operands"]["tflops"], 4)
+            line["mfma_power_cap"] = cap
         if world == 1 and not args.no_clip:
             line["clip"] = clip_wall_clock(model, dev, args.clip_steps)
         if world == 1 and not args.no_extra_legs:

@@ -183,6 +183,16 @@ int aether_groupnorm_apply(const void* x, int NB, int T, int H, int W, int C, co
                            int oT, int oH, int oW, int pt, int ph, int pw, const float* cond, int zT, int zH, int zW,
                            const int* tmap_host, void* stream);
 
+/* The same with the causal front of CogVideoXCausalConv3d's input written by the same launch (the conv that follows pads two
+ * frames in front: autoencoder_kl_cogvideox.py CogVideoXCausalConv3d.fake_context_parallel_forward / conv_cache, reached from
+ * P:557-618 and P:931,936): y is [NB, T+2, oH, oW, C]; frames 0, 1 <- front_prev (the last two padded frames of the previous
+ * frame chunk, [NB, 2, oH, oW, C]) or, when front_prev is NULL (first chunk), copies of normalised frame 0; the last two frames
+ * of y are also stored to front_next (same shape) for the next chunk.  Only interiors of the caches are read or written.
+ * Replaces aether_groupnorm_apply + aether_causal_front (which stays for callers that pad a volume they did not normalise). */
+int aether_groupnorm_apply_causal(const void* x, int NB, int T, int H, int W, int C, const float* affine, int silu_flag, void* y,
+                                  int oH, int oW, int ph, int pw, const float* cond, int zT, int zH, int zW, const int* tmap_host,
+                                  const void* front_prev, void* front_next, void* stream);
+
 /* Causal front of a convolution input vol [NB, Tp, Hp, Wp, C] whose frames 2..Tp-1 are already written (CogVideoXCausalConv3d:
  * two frames of temporal context in front, from the previous chunk's `conv_cache` or by repeating the first frame):
  * frames 0,1 := prev [NB, 2, Hp, Wp, C], or copies of frame 2 when prev is NULL;  next [NB, 2, Hp, Wp, C] := the last two

@@ -383,6 +383,38 @@ def test_causal_front_single_launch(cuda, hip_lib, T):
         assert torch.equal(vol, ref) and torch.equal(cache["k"], ref[:, -2:])
 
 
+@pytest.mark.parametrize("Cc,T,spatial", [(64, 1, False), (128, 2, False), (64, 5, True), (256, 1, True), (512, 3, False)])
+def test_groupnorm_apply_with_fused_causal_front(cuda, hip_lib, Cc, T, spatial):
+    """aether_groupnorm_apply_causal (norm + front frames + cache for the next chunk in ONE launch, what the C launch plan issues)
+    against aether_groupnorm_apply followed by aether_causal_front, over two consecutive chunks (no cache, then with a cache):
+    the padded volumes are bit-identical and the caches agree on their interiors (the fused form never touches cache borders)."""
+    from aether_amd.vae import _Norm
+    from oracle.vae import SpatialNorm3D
+    g = torch.Generator().manual_seed(100 * Cc + T)
+    NB, H, W = 2, 8, 12
+    vae = _vae(cuda)
+    if spatial:
+        sn = SpatialNorm3D(Cc, 16, 32)
+        with torch.no_grad():
+            for name, p in sn.named_parameters():
+                p.copy_(torch.randn(p.shape, generator=g) * (0.3 if p.dim() > 1 else 0.1))
+            sn.norm_layer.weight.add_(1.0)
+        n = _Norm({"s." + k: v for k, v in sn.state_dict().items()}, "s.", cuda, True)
+    else:
+        n = _Norm({"w.weight": 1 + 0.1 * torch.randn(Cc, generator=g), "w.bias": 0.1 * torch.randn(Cc, generator=g)}, "w.", cuda, False)
+    cache_a, cache_b = {}, {}
+    for chunk in range(2):
+        x = (torch.randn(NB, T, H, W, Cc, generator=g) * 2 + 0.3).to(torch.bfloat16).to(cuda)
+        zq = torch.randn(NB, max(1, (T + 1) // 2), H // 4, W // 4, 16, generator=g).to(torch.bfloat16).to(cuda) if spatial else None
+        ref = vae._norm_to_padded(x, n, 2, 1, True, zq).clone()
+        vae._causal_front(ref, cache_a, "k")
+        out = vae._norm_to_padded(x, n, 2, 1, True, zq, causal=(cache_b, "k")).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), (chunk, float((out.float() - ref.float()).abs().max()))
+        assert torch.equal(cache_b["k"][:, :, 1:-1, 1:-1], cache_a["k"][:, :, 1:-1, 1:-1])
+        assert torch.equal(cache_a["k"], ref[:, -2:])
+
+
 @pytest.mark.parametrize("cin,cout,NB,T,H,W,kt,res", [(128, 128, 1, 2, 12, 20, 3, False), (64, 256, 2, 3, 9, 33, 3, True),
                                                       (256, 128, 1, 1, 30, 45, 3, True), (128, 256, 2, 2, 16, 24, 1, False),
                                                       (64, 128, 3, 1, 5, 7, 1, True), (512, 512, 1, 2, 40, 61, 3, False)])

@@ -12,7 +12,37 @@ __global__ __launch_bounds__(SHAPE == 2 ? 512 : 256) void mfma_probe(const bf16x
     const int lane = threadIdx.x & 63;
     const unsigned long long c0 = __builtin_readcyclecounter(), r0 = wall_clock64();
     float keep = 0.f;
-    if (SHAPE == 0) {                       // 32x32x16, 4x4 accumulator tiles (128x128 per wave): 16 MFMAs per k-step of 16
+    if (SHAPE == 3 || SHAPE == 4) {         // as shape 0 with the 16 MFMAs of a k-step in snake order (one operand changes per step: 3), or
+                                            // with ONE operand pair for every MFMA (nothing ever changes on the operand buses: 4)
+        bf16x8 a[2][4], b[2][4];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[s][i] = src[(s * 8 + i) * 64 + lane]; b[s][i] = src[(s * 8 + 4 + i) * 64 + lane]; }
+        f32x16 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int j = (i & 1) ? 3 - jj : jj;
+                        if (SHAPE == 3) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][0], b[0][0], acc[i][j], 0, 0, 0);
+                    }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) keep += acc[i][j][0] + acc[i][j][7];
+    } else if (SHAPE == 0) {                // 32x32x16, 4x4 accumulator tiles (128x128 per wave): 16 MFMAs per k-step of 16
         bf16x8 a[2][4], b[2][4];
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -101,6 +131,8 @@ extern "C" int run_mfma_probe(int shape, int nwaves, const void* src, int iters,
     hipStream_t s = (hipStream_t)stream;
     if (shape == 0) hipLaunchKernelGGL((mfma_probe<0>), grid, block, 0, s, (const bf16x8*)src, iters, out, sink);
     else if (shape == 1) hipLaunchKernelGGL((mfma_probe<1>), grid, block, 0, s, (const bf16x8*)src, iters, out, sink);
+    else if (shape == 3) hipLaunchKernelGGL((mfma_probe<3>), grid, block, 0, s, (const bf16x8*)src, iters, out, sink);
+    else if (shape == 4) hipLaunchKernelGGL((mfma_probe<4>), grid, block, 0, s, (const bf16x8*)src, iters, out, sink);
     else hipLaunchKernelGGL((mfma_probe<2>), grid, block, 0, s, (const bf16x8*)src, iters, out, sink);
     return (int)hipGetLastError();
 }

@@ -22,14 +22,24 @@ def _sources():
     return sorted(CSRC.glob("*.hip"))
 
 
+def _code_only(text: str) -> str:
+    """Source text without comments and with white space collapsed: what the compiler sees, give or take (string literals that
+    contain comment markers would be clipped too — the same way every time, which is all a digest needs)."""
+    import re
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    return re.sub(r"\s+", " ", text).strip()
+
+
 def source_digest() -> str:
-    """sha256 (first 16 hex digits) over the kernel sources and the C header: stamps profiles so that a summary taken from an
-    older build of the kernels is recognised as stale (bench.py's roofline.traffic, tools/summarize_rocprof.py)."""
+    """sha256 (first 16 hex digits) over the CODE of the kernel sources and the C header (comments and white space do not count:
+    editing a comment must not make a measured profile look stale): stamps profiles so that a summary taken from an older build
+    of the kernels is recognised as such (bench.py's roofline.traffic, tools/summarize_rocprof.py)."""
     import hashlib
     h = hashlib.sha256()
     for f in sorted(list(_sources()) + list(CSRC.glob("*.hpp")) + [CSRC.parent.parent / "include" / "aether_hip.h"]):
         h.update(f.name.encode())
-        h.update(f.read_bytes())
+        h.update(_code_only(f.read_text()).encode())
     return h.hexdigest()[:16]
 
 

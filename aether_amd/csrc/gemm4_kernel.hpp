@@ -10,10 +10,11 @@
 //     (profiles/r02_mfma_power_probe.json; 2.48 PF/s only on all-zero operands); this loop runs at 1.55-1.8 GHz;
 //   * LDS-DMA alone needs 1.2-1.45 us per 64-wide K tile (64 KiB per CU, 80 % L2 hits) at 2.39 GHz, however many requests are in
 //     flight (two 64-KiB buffers or this ring: the same) — the same time the MFMAs alone need (1.2 us at 1.9 GHz);
-//   * together they take 1.65 us: only 5 % of that is spent in s_waitcnt / s_barrier, the rest is the MFMA stream waiting behind
-//     its own blocked LDS-DMA issue (one wave per SIMD cannot issue an MFMA while its previous instruction is held at the
-//     texture-addresser queue).  The vendor GEMM (same 256x256x64 tile, 4 waves, direct-to-LDS, same L2 hit rate) is within 2 % of
-//     our ping-pong loop over the four DiT shapes (profiles/r02_vendor_gemm.txt).
+//   * per 64-wide K tile (timers included, 8192^3): MFMAs alone 1.24 us = 2 480 cycles at 2.00 GHz; + fragment reads 1.40 us =
+//     2 550 cycles at 1.82 GHz; + LDS-DMA 1.68 us = 2 670 cycles at 1.59 GHz, of which 5 % in s_waitcnt / s_barrier: switching the
+//     data movement on costs 7 % in cycles and 20 % in clock — the loop is bound by the power cap, not by its schedule.  The
+//     vendor GEMM (same 256x256x64 tile, 4 waves, direct-to-LDS, same L2 hit rate and miss bytes) is within 2-5 % of our
+//     ping-pong loop over the four DiT shapes (profiles/r02_vendor_gemm.txt).
 // Design notes: with two 64-wide buffers a slab can only be requested one tile-time before it is needed; the ring requests slab
 // s+4 while slab s is computed and only ever waits for the OLDEST of three requests in flight (s_waitcnt vmcnt(16)), and the
 // LDS-DMA instructions are spread one behind every fourth MFMA.

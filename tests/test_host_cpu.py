@@ -157,3 +157,15 @@ def test_vae_state_dict_spec_matches_oracle_keys():
         spec = AetherVAE(kw, device="cpu").state_dict_spec()
         ref = {k: tuple(v.shape) for k, v in OracleVAE(VaeConfig(**kw)).state_dict().items()}
         assert spec == ref
+
+
+def test_source_digest_ignores_comments_and_white_space():
+    """Profiles are stamped with a digest of the kernel CODE (aether_amd/build.py): a comment or re-indentation must not make a
+    measured profile look stale, a code change must."""
+    from aether_amd.build import _code_only, source_digest
+    a = "int f(int x) {\n    return x + 1;   // add one\n}\n"
+    b = "/* header */ int f(int x) { return x + 1; }"
+    c = "int f(int x) { return x + 2; }"
+    assert _code_only(a) == _code_only(b) != _code_only(c)
+    d = source_digest()
+    assert len(d) == 16 and d == source_digest()

@@ -192,6 +192,8 @@ template <int N, class F> AE_DEV void static_for(F&& f) { static_for_impl(f, std
 // only speed: results are those of an exact soft-max in fp32 either way.  AETHER_ATTN_EXACT_MAX (no bound table) refreshes on
 // every tile.
 constexpr float FA_SHIFT_SPAN = 100.f;
+constexpr float FA_SUM_LIMIT = 1.2676506e30f;   // 2^100: a lane's partial sum of one tile (32 terms) above this => refresh the shift
+constexpr float FA_SUM_FLOOR = 7.8886091e-31f;  // 2^-100: a finished row sum below this (shift-0 sweep) => the row is redone with a true shift
 constexpr int FA_KMAX_SLOTS = 1024;   // per-tile bounds of one (batch, head) staged in LDS: S <= 65 536 (longer rows refresh every tile)
 
 AE_DEV float fa_row_norm2(const bf16x8 (&qf)[4]) {
@@ -214,23 +216,36 @@ AE_DEV float fa_tile_max(const f32x16 (&sc)[2]) {
     return fmaxf(a, __shfl_xor(a, 32, 64));
 }
 
-// exponentiate a score tile that already carries its shift; P fragments + partial row sum
-AE_DEV void fa_exp_tile(const f32x16 (&sc)[2], bf16x8 (&pf)[2][2], float& l_run) {
+// exp2 of two scores -> one packed bf16 pair of P (v_cvt_pk_bf16_f32) + row-sum update.
+// DOT2: the row sum is taken from the ROUNDED pair with one v_dot2c_f32_bf16 against (1, 1) — one VALU issue per two scores instead of
+// two v_add_f32, and the denominator then sums exactly the values the P·V MFMA multiplies (numerator and denominator round alike).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <bool DOT2>
+AE_DEV unsigned fa_exp_pair(float a, float b, float& s0, float& s1) {
+    const float pa = __builtin_amdgcn_exp2f(a), pb = __builtin_amdgcn_exp2f(b);
+    const unsigned w = pack_bf16x2(pa, pb);
+    if (DOT2) {
+        bf16x2 ones;
+        ones[0] = (__bf16)1.0f; ones[1] = (__bf16)1.0f;
+        s0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w), ones, s0, false);
+    } else {
+        s0 += pa; s1 += pb;
+    }
+    return w;
+}
+
+// exponentiate a score tile that already carries its shift; P fragments (packed bf16 pairs) + this lane's partial sum of the tile
+template <bool DOT2>
+AE_DEV float fa_exp_tile(const f32x16 (&sc)[2], u32x4 (&pf)[2][2]) {
     float psum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            float pv[8];
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                pv[e] = __builtin_amdgcn_exp2f(sc[t][8 * s + e]);
-                psum[e & 3] += pv[e];
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) pf[t][s][e] = (__bf16)pv[e];
-        }
-    l_run += (psum[0] + psum[1]) + (psum[2] + psum[3]);
+            for (int e = 0; e < 4; ++e)
+                pf[t][s][e] = fa_exp_pair<DOT2>(sc[t][8 * s + 2 * e], sc[t][8 * s + 2 * e + 1], psum[DOT2 ? (e & 1) + 2 * (s & 1) : 2 * (e & 1)], psum[2 * (e & 1) + 1]);
+    return (psum[0] + psum[1]) + (psum[2] + psum[3]);
 }
 
 // =================================================================================================================
@@ -243,13 +258,16 @@ AE_DEV void fa_exp_tile(const f32x16 (&sc)[2], bf16x8 (&pf)[2][2], float& l_run)
 // (QK^T of the second 32-key half under the exponentials of the first, P·V of the first half under the exponentials of the second):
 // VALU issued between a wave's own MFMAs hides under them, VALU of the OTHER waves of the SIMD mostly does not
 // (profiles/r01_valu_probe.jsonl: 680 vs 1027 cycles for 16 MFMAs + one tile's soft-max).
-template <bool WIDE_STORE, int NW, int PRIO = 1, int ILV = 0>
+// DOT2 = row sums by v_dot2c_f32_bf16 from the rounded P pairs (fa_exp_pair).
+// QREG (ILV = 2 only) = the tile-pair loop keeps the Q fragments in 16 registers (the optimistic sweep has no shift vector to hold) instead of
+// re-reading them from LDS: 8 of the 24 ds_read_b128 per tile go away.
+template <bool WIDE_STORE, int NW, int PRIO = 1, int ILV = 0, bool DOT2 = false, bool QREG = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))   // <= 128 VGPRs: 16 waves per CU
 void flash_attn_fwd_kernel(FlashArgs p) {
     // 2 x (K tile + V^T tile) + this workgroup's Q fragments (4 KiB per wave, lane-linear: conflict-free ds_read_b128).  Q lives in
     // LDS, not in 16 registers per lane: the registers hold the soft-max shift vector instead (see below) and the kernel stays
     // within the 128-register budget of 4 waves per SIMD without spilling.
-    __shared__ __attribute__((aligned(16))) char smem[2 * FA_BUF + NW * 4096 + FA_KMAX_SLOTS * 4];
+    __shared__ __attribute__((aligned(16))) char smem[2 * FA_BUF + NW * 4096 + (ILV == 1 ? FA_KMAX_SLOTS * 4 : 0) + 64];
     const FaLane L = fa_lane_setup();
     const int tid = threadIdx.x, hi = L.hi;
 
@@ -310,17 +328,24 @@ void flash_attn_fwd_kernel(FlashArgs p) {
     // max||k||^2 of every KV tile of this (batch, head) -> LDS (the per-tile guard reads it with one broadcast ds_read_b32: a
     // global load inside the loop would share vmcnt with the K/V DMA and serialise it)
     float* const kms = (float*)(smem + 2 * FA_BUF + NW * 4096);
-    const bool bounded = p.kmax2 != nullptr && nkv <= FA_KMAX_SLOTS;
+    float* const votes = (float*)(smem + 2 * FA_BUF + NW * 4096 + (ILV == 1 ? FA_KMAX_SLOTS * 4 : 0));   // 8 floats of their own
+    const bool bounded = ILV == 1 && p.kmax2 != nullptr && nkv <= FA_KMAX_SLOTS;
     if (bounded)
         for (int i = tid; i < nkv; i += NW * 64) kms[i] = p.kmax2[(size_t)bh * (p.Spad / FA_KVBLK) + i];
     drain_and_barrier();
 
+    // Generic tile.  Tile 0 of a row refreshes (the shift becomes the tile's true maximum).  Every later tile is exponentiated
+    // OPTIMISTICALLY against the standing shift — no tile maximum, no subtraction (the shift rides in the MFMA's C operand), no
+    // rescale — and checked afterwards: if a lane's partial sum of the tile exceeds 2^100 (some p overflowed or came close; NaN
+    // fails the comparison too) the wave takes the classic online step on the scores it still holds — tile maximum, shift update,
+    // rescale of o and l, in place — and exponentiates again.  One v_cmp + one vote per tile instead of a 32-way maximum; no bound
+    // table, no dependence on the weights: the cost of the exact path is data independent up to those (rare, self-limiting —
+    // every refresh raises the shift to a true maximum) repeats.
     auto tile = [&](int j, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;     // the last tile: nothing to stage, ragged tail masked
         const int cur = j & 1;
         if (!LAST) stage(j + 1, cur ^ 1);
         const char* base = smem + cur * FA_BUF;
-        const float km2 = bounded ? kms[j] : INFINITY;
 
         f32x16 sc[2];
         if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
@@ -336,8 +361,15 @@ void flash_attn_fwd_kernel(FlashArgs p) {
         if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
         if (LAST && ragged) fa_mask_tail(sc, j, hi, S);
 
-        if (__builtin_expect(!__all(qn2 * km2 <= thr2), 0)) {
-            // refresh (tile 0 of every row; otherwise rare): sc holds s - m_run; bring the shift up to this tile's maximum, in place
+        u32x4 pf[2][2];
+        float tsum = 0.f;
+        bool redo = (j == 0);
+        if (!redo) {
+            tsum = fa_exp_tile<DOT2>(sc, pf);
+            redo = __any(!(tsum <= FA_SUM_LIMIT)) != 0;
+        }
+        if (__builtin_expect(redo, 0)) {
+            // sc holds s - m_run; bring the shift up to this tile's maximum, in place
             const float rel = fa_tile_max(sc);
             const float up = (j == 0) ? rel : fmaxf(rel, 0.f);   // first tile: the shift becomes the tile's true maximum
             if (__any(up != 0.f)) {
@@ -353,9 +385,9 @@ void flash_attn_fwd_kernel(FlashArgs p) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { sc[0][i] -= up; sc[1][i] -= up; negm[i] = -m_run; }
             }
+            tsum = fa_exp_tile<DOT2>(sc, pf);                      // sc = s - m_run <= 0 wherever the shift moved
         }
-        bf16x8 pf[2][2];
-        fa_exp_tile(sc, pf, l_run);                               // sc = s - m_run <= FA_SHIFT_SPAN (<= 0 after a refresh)
+        l_run += tsum;
 
         // ---- O^T += V^T . P^T ----
         if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
@@ -366,7 +398,7 @@ void flash_attn_fwd_kernel(FlashArgs p) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const bf16x8 vf = *(const bf16x8*)(base + dt * 4096 + L.voff[t][s]);
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[t][s], o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pf[t][s]), o[dt], 0, 0, 0);
                 }
         if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
         if (!LAST) drain_and_barrier();
@@ -380,18 +412,17 @@ void flash_attn_fwd_kernel(FlashArgs p) {
         auto Qf = [&](int ks) { return *(const bf16x8*)(qs + ks * 1024); };
         auto Vf = [&](int dt, int t, int s2) { return *(const bf16x8*)(base + dt * 4096 + L.voff[t][s2]); };
         f32x16 s0, s1;
-        bf16x8 pf[2][2];
+        u32x4 pf[2][2];
         // (row sums as v_pk_fma_f32 with a register of ones — 6 cycles per two elements in isolation — measured 3 % SLOWER here than
         // plain v_add_f32, as in round 1's lock-step kernel: profiles/r02_attn_variants.txt)
         float ps[4] = {0.f, 0.f, 0.f, 0.f};
         // one quarter (4 scores) of a 32-key half: exp2, row sum, bf16 P fragment elements
         auto quarter = [&](const f32x16& sc, int t, int q) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float pv = __builtin_amdgcn_exp2f(sc[4 * q + e]);
-                ps[e] += pv;
-                asm volatile("" : "+v"(ps[e]));      // keep the row-sum add inside this group (IR passes re-associate and sink it otherwise)
-                pf[t][q >> 1][4 * (q & 1) + e] = (__bf16)pv;
+            for (int e = 0; e < 2; ++e) {
+                const unsigned w = fa_exp_pair<DOT2>(sc[4 * q + 2 * e], sc[4 * q + 2 * e + 1], ps[2 * e], ps[2 * e + 1]);
+                asm volatile("" : "+v"(ps[2 * e]), "+v"(ps[2 * e + 1]));      // keep the row-sum update inside this group (IR passes re-associate and sink it otherwise)
+                pf[t][q >> 1][2 * (q & 1) + e] = w;
             }
         };
         bf16x8 fa = Kf(0, 0), fq = Qf(0);
@@ -418,7 +449,7 @@ void flash_attn_fwd_kernel(FlashArgs p) {
         for (int g = 0; g < 4; ++g) {
             const int s2 = g >> 1, dt = g & 1;
             const bf16x8 na = g < 3 ? Vf((g + 1) & 1, 0, (g + 1) >> 1) : Vf(0, 1, 0);
-            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, pf[0][s2], o[dt], 0, 0, 0);
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_bit_cast(bf16x8, pf[0][s2]), o[dt], 0, 0, 0);
             fa = na;
             __builtin_amdgcn_sched_barrier(0);
             quarter(s1, 1, g);
@@ -429,7 +460,7 @@ void flash_attn_fwd_kernel(FlashArgs p) {
         for (int g = 0; g < 4; ++g) {
             const int s2 = g >> 1, dt = g & 1;
             const bf16x8 na = g < 3 ? Vf((g + 1) & 1, 1, (g + 1) >> 1) : fa;
-            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, pf[1][s2], o[dt], 0, 0, 0);
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_bit_cast(bf16x8, pf[1][s2]), o[dt], 0, 0, 0);
             fa = na;
         }
         l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
@@ -456,6 +487,11 @@ void flash_attn_fwd_kernel(FlashArgs p) {
     };
     [[maybe_unused]] auto pair_loop = [&](int npairs) {
         float ps[4] = {0.f, 0.f, 0.f, 0.f};
+        bf16x8 qreg[4];
+        if (QREG) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qreg[ks] = *(const bf16x8*)(qs + ks * 1024);
+        }
         // K(1) -> buffer 1 now, V(1) after the barrier that publishes it (K(0), V(0) were staged and published by the prologue)
         stage_k(1, 1);
         drain_and_barrier();
@@ -463,7 +499,7 @@ void flash_attn_fwd_kernel(FlashArgs p) {
         for (int pi = 0; pi < npairs; ++pi) {
             const int j = 2 * pi;
             f32x16 S[4];
-            bf16x8 pf[4][2];
+            u32x4 pf[4][2];
             const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             // A-operand fragment of MFMA step i (0..31): QK h0 0-3, QK h1 4-7, QK h2 8-11, PV h0 12-15, QK h3 16-19, PV h1 20-23, PV h2 24-27, PV h3 28-31
             auto afrag = [&](auto I) -> bf16x8 {
@@ -478,16 +514,13 @@ void flash_attn_fwd_kernel(FlashArgs p) {
             // one eighth (2 scores) of a half's soft-max
             auto eighth = [&](auto H, auto E) {
                 constexpr int h = decltype(H)::value, e = decltype(E)::value;
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const float pv = __builtin_amdgcn_exp2f(S[h][2 * e + u]);
-                    ps[2 * (e & 1) + u] += pv;
-                    asm volatile("" : "+v"(ps[2 * (e & 1) + u]));
-                    pf[h][e >> 2][2 * (e & 3) + u] = (__bf16)pv;
-                }
+                // DOT2: two alternating accumulators (ps[0], ps[2]); otherwise four add chains as before
+                const unsigned w = fa_exp_pair<DOT2>(S[h][2 * e], S[h][2 * e + 1], ps[2 * (e & 1)], ps[2 * (e & 1) + 1]);
+                asm volatile("" : "+v"(ps[2 * (e & 1)]), "+v"(ps[2 * (e & 1) + 1]));
+                pf[h][e >> 2][e & 3] = w;
             };
             // A-operand fragments are fetched TWO MFMAs ahead (fa: this step, fb: next step, loaded now: the step after), Q fragments one
-            bf16x8 fa = afrag(ic<0>{}), fb = afrag(ic<1>{}), fq = *(const bf16x8*)(qs);
+            bf16x8 fa = afrag(ic<0>{}), fb = afrag(ic<1>{}), fq = QREG ? qreg[0] : *(const bf16x8*)(qs);
             static_for<24>([&](auto I) {                                   // steps 0..23 (up to barrier X)
                 constexpr int i = decltype(I)::value;
                 constexpr int grp = i >> 2, m = i & 3;
@@ -497,10 +530,10 @@ void flash_attn_fwd_kernel(FlashArgs p) {
                 if constexpr (i + 2 < 24) nb = afrag(ic<i + 2>{});
                 if constexpr (i + 1 < 24) {
                     constexpr int g2 = (i + 1) >> 2;
-                    if constexpr (g2 == 0 || g2 == 1 || g2 == 2 || g2 == 4) nq = *(const bf16x8*)(qs + ((i + 1) & 3) * 1024);
+                    if constexpr (g2 == 0 || g2 == 1 || g2 == 2 || g2 == 4) nq = QREG ? qreg[(i + 1) & 3] : *(const bf16x8*)(qs + ((i + 1) & 3) * 1024);
                 }
                 if constexpr (qk) S[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fq, m == 0 ? zero : S[h], 0, 0, 0);
-                else o[m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, pf[h][m >> 1], o[m & 1], 0, 0, 0);
+                else o[m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_bit_cast(bf16x8, pf[h][m >> 1]), o[m & 1], 0, 0, 0);
                 fa = fb; fb = nb; fq = nq;
                 __builtin_amdgcn_sched_barrier(0);
                 // VALU partner: groups 1,2 -> sm h0 (eighths 0-3, 4-7); 3,4 -> sm h1; 5 -> sm h2 first half
@@ -521,7 +554,7 @@ void flash_attn_fwd_kernel(FlashArgs p) {
             static_for<4>([&](auto M) {                                    // PV h2 ∥ sm h3 a
                 constexpr int m = decltype(M)::value;
                 const bf16x8 nb = afrag(ic<26 + m>{});                     // step 24+m+2 (26..29)
-                o[m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, pf[2][m >> 1], o[m & 1], 0, 0, 0);
+                o[m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_bit_cast(bf16x8, pf[2][m >> 1]), o[m & 1], 0, 0, 0);
                 fa = fb; fb = nb;
                 __builtin_amdgcn_sched_barrier(0);
                 eighth(ic<3>{}, ic<m>{});
@@ -533,7 +566,7 @@ void flash_attn_fwd_kernel(FlashArgs p) {
                 constexpr int m = decltype(M)::value;
                 bf16x8 nb = fb;
                 if constexpr (m < 2) nb = afrag(ic<30 + m>{});
-                o[m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, pf[3][m >> 1], o[m & 1], 0, 0, 0);
+                o[m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_bit_cast(bf16x8, pf[3][m >> 1]), o[m & 1], 0, 0, 0);
                 fa = fb; fb = nb;
             });
             // Y: V(j+1) consumed; K,V(j+2), K(j+3) have landed
@@ -544,47 +577,43 @@ void flash_attn_fwd_kernel(FlashArgs p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 
-    if (ILV == 2) {
-        // workgroup vote: every row of every wave bounded outright?  (max over the head's tiles of max||k||^2, then ||q||^2 of each row)
-        float* const votes = kms + FA_KMAX_SLOTS - 8;                      // the last 8 slots of the bound table (nkv <= FA_KMAX_SLOTS - 8 checked)
-        float kall = 0.f;
-        const bool can_vote = bounded && nkv <= FA_KMAX_SLOTS - 8 && nkv >= 4;
-        if (can_vote) {
-            for (int i = L.lane; i < nkv; i += 64) kall = fmaxf(kall, kms[i]);
-            kall = wave_max(kall);
-        }
-        const bool mine = can_vote && __all(qn2 * kall <= FA_SHIFT_SPAN * FA_SHIFT_SPAN) != 0;
-        block_barrier();                                                    // every wave has read its slice of kms
+    if (ILV == 2 && nkv >= 4) {
+        // OPTIMISTIC sweep with shift 0 (no a-priori bound, no dependence on the weights): the tile-pair loop exponentiates the raw
+        // log2-domain scores.  That is an exact soft-max (shift invariance) unless some exp2 left fp32's range — which shows in the
+        // finished row: a row sum that is not finite, or so small that its terms were flushed, or a non-finite accumulator.  The
+        // waves of the workgroup vote once, at the end; if any row failed, the whole workgroup (the loops' barrier patterns differ, so
+        // the choice must be workgroup-uniform) starts over with the generic tiles, whose shift is a true maximum.  |log2-domain
+        // score| > 100 means |q·k|/8 > 69 in natural units: unseen with LayerNorm-ed q, k; the cost then is one wasted sweep.
+        const int npairs = (nkv - 1) / 2;                               // the last tile (ragged tail, no staging) stays with the generic tile
+        pair_loop(npairs);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) negm[i] = 0.f;                     // (re-materialised here: the shift vector is dead across the pair loop)
+        int j = 2 * npairs;
+        for (; j < nkv - 1; ++j) tile(j, std::false_type{});           // K,V(j) are in place and published; the generic tile stages j+1 itself
+        tile(nkv - 1, std::true_type{});
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        float chk = 0.f;                                                // 0 * inf = NaN: any non-finite accumulator poisons chk
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { chk = fmaf(o[0][i], 0.f, chk); chk = fmaf(o[1][i], 0.f, chk); }
+        const bool mine = __all(l_tot >= FA_SUM_FLOOR && l_tot < INFINITY && chk == 0.f) != 0;     // NaN fails every comparison
+        block_barrier();                                                // every wave is past its last LDS read
         if (L.lane == 0) votes[L.wave] = mine ? 1.f : 0.f;
         block_barrier();
         bool all_ok = true;
 #pragma unroll
         for (int w = 0; w < NW; ++w) all_ok = all_ok && (votes[w] != 0.f);
-        int j = 0;
-        if (all_ok) {
-            const int npairs = (nkv - 1) / 2;                               // the last tile (ragged tail, no staging) stays with the generic tile
-            pair_loop(npairs);
-            j = 2 * npairs;
-            thr2 = FA_SHIFT_SPAN * FA_SHIFT_SPAN;                           // shift 0 stays valid for the one or two tiles left
-            if (j < nkv - 1) {                                              // K,V(j) are in place and published; the generic tile stages j+1 itself
-                tile(j, std::false_type{});
-                ++j;
-            }
-        } else {
-            // not bounded outright: the guarded one-tile paths (tile 0 refreshes, passing tiles interleaved, generic after a failure)
-            if (nkv > 1) { tile(0, std::false_type{}); j = 1; }
-            float km = (bounded && j < nkv) ? kms[j] : INFINITY;
-            for (; j < nkv - 1; ++j) {
-                if (!__all(qn2 * km <= thr2)) break;
-                km = kms[j + 1];
-                asm volatile("" : "+v"(km));
-                tile_ilv(j);
-            }
-            for (; j < nkv - 1; ++j) tile(j, std::false_type{});
+        if (!all_ok) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; negm[i] = 0.f; }
+            m_run = 0.f; l_run = 0.f;
+            stage(0, 0);
+            drain_and_barrier();
+            for (int jj = 0; jj < nkv - 1; ++jj) tile(jj, std::false_type{});
+            tile(nkv - 1, std::true_type{});
         }
     } else if (ILV == 1) {
-        // Tile 0 always refreshes.  After it, passing tiles run in the interleaved loop; the first tile that fails the guard sends
-        // the wave to the generic loop for the rest of its sweep (exact as well, just not interleaved).
+        // Tile 0 always refreshes.  After it, tiles that pass the a-priori guard (needs the bound table) run in the interleaved loop; the
+        // first tile that fails sends the wave to the generic loop for the rest of its sweep (exact as well, just not interleaved).
         int j = 0;
         if (nkv > 1) { tile(0, std::false_type{}); j = 1; }
         float km = (bounded && j < nkv) ? kms[j] : INFINITY;          // bound of the tile about to run, fetched one tile ahead
@@ -595,10 +624,11 @@ void flash_attn_fwd_kernel(FlashArgs p) {
             tile_ilv(j);
         }
         for (; j < nkv - 1; ++j) tile(j, std::false_type{});
+        tile(nkv - 1, std::true_type{});
     } else {
         for (int j = 0; j < nkv - 1; ++j) tile(j, std::false_type{});
+        tile(nkv - 1, std::true_type{});
     }
-    tile(nkv - 1, std::true_type{});
 
     fa_store<WIDE_STORE>(o, l_run, p, bh, qrow, hi);
 }
@@ -613,9 +643,6 @@ void flash_attn_fwd_kernel(FlashArgs p) {
 // (1027 cycles) — so the overlap has to be built inside each wave: the loop body carries two score tiles and two P
 // fragments (sc/pf of tile j being soft-maxed, sc of tile j+1 being produced, pf of tile j-1 being consumed).
 constexpr int FA_NB = 4;  // K/V ring depth (tile t lives in slot t & 3)
-
-
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 
 // Timing ablations of this kernel (profiles/r01_attn_swp_ablation.json, shader cycles per KV tile for the two waves of
@@ -810,6 +837,280 @@ __global__ __launch_bounds__(512) void flash_attn_swp_kernel(FlashArgs p) {
     fa_store<WIDE_STORE>(o, l_run, p, bh, qrow, hi);
 }
 
+
+// =================================================================================================================
+// 64-rows-per-wave kernel (AETHER_ATTN_ROWS64): every K / V fragment read from LDS feeds TWO MFMAs
+// =================================================================================================================
+// What limits the 32-row kernels above is not the matrix pipe (57-66 % busy) but the wave's own issue stream: per KV tile a wave issues,
+// besides 16 MFMAs and ~80 soft-max VALU, 16-24 ds_read_b128, two LDS-DMA pieces, waits and a barrier (keeping the Q fragments in
+// registers — 8 reads fewer per tile — measured +4 %, profiles/r03_attn_variants.txt).  Here a wave owns 64 query rows (two 32-row blocks):
+// the K fragment of a k-step multiplies both blocks' Q fragments and the V fragment both blocks' P fragments, so K/V fragment reads per
+// MFMA drop from 1 to 0.5, Q lives in registers (0 reads), and a workgroup of 4 waves (256 rows, as before) stages the same 16 KiB per
+// KV tile with half the DMA instructions per MFMA.  256 registers per lane -> two waves per SIMD (two workgroups per CU).
+//
+// Schedule (software pipeline over 32-key halves; scA / scB = scores of an even / odd half, pfA / pfB its P fragments); iteration j:
+//   slot 1   QK(tile j, keys 32-63) -> scB      ∥ soft-max of scA, block 0 -> pfA[0]
+//   slot 2   PV(tile j-1, keys 32-63) with pfB  ∥ soft-max of scA, block 1 -> pfA[1]
+//   slot 3   QK(tile j+1, keys 0-31) -> scA     ∥ soft-max of scB, block 0 -> pfB[0]
+//   slot 4   PV(tile j, keys 0-31) with pfA     ∥ soft-max of scB, block 1 -> pfB[1]
+//   s_waitcnt vmcnt(0); s_barrier;  LDS-DMA of K(j+3) and V(j+2) into the ring slots K(j) and V(j-1) just left
+// Every slot is 8 MFMAs (4 fragments, each used twice) with the soft-max of two scores of the wave's own rows behind each MFMA.
+// K and V live in separate rings of three 8 KiB slots (48 KiB per workgroup): a tile's DMA has a whole iteration to land.
+// Soft-max: the optimistic shift-0 sweep of the tile-pair kernel (exact by shift invariance unless an exp2 left fp32's range, which the
+// finished rows show; the workgroup then votes and redoes its sweep with the classic online soft-max, `rows64_conservative`).
+// NW = 4: 256-row workgroups, two per CU;  NW = 8 (AETHER_ATTN_WG512): 512-row workgroups, one per CU — every staged KV tile then serves twice
+// the MFMAs, i.e. half the LDS-DMA instructions per MFMA (an LDS-DMA piece costs its issuing wave 60-185 cycles).
+template <bool WIDE_STORE, bool DOT2, int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void flash_attn_rows64_kernel(FlashArgs p) {
+    constexpr int RING = 3;
+    constexpr int PASSES = 8 / NW;
+    __shared__ __attribute__((aligned(16))) char smem[2 * RING * FA_TILE + 64];
+    char* const kring = smem;
+    char* const vring = smem + RING * FA_TILE;
+    float* const votes = (float*)(smem + 2 * RING * FA_TILE);
+    const FaLane L = fa_lane_setup();
+    const int tid = threadIdx.x, hi = L.hi;
+    int voff[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) voff[t][s2] = L.voff[t][s2] - FA_TILE;      // relative to the V tile
+
+    const int wgid = xcd_remap(blockIdx.x, p.nwg);
+    const int bh = wgid / p.nqb;
+    const int qb = wgid - bh * p.nqb;
+    const int S = p.S;
+    const bf16_t* Qg = p.Q + (size_t)bh * S * FA_D;
+    const bf16_t* Kg = p.K + (size_t)bh * S * FA_D;
+    const bf16_t* Vg = p.Vt + (size_t)bh * FA_D * p.Spad;
+
+    // ---- Q fragments of both 32-row blocks, in registers for the whole sweep --------------------------------------------------------------
+    int qrow[2];
+    bf16x8 qf[2][4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        qrow[b] = qb * (NW * 64) + L.wave * 64 + b * 32 + L.l32;
+        const int qc = min(qrow[b], S - 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[b][ks] = *(const bf16x8*)(Qg + (size_t)qc * FA_D + 16 * ks + 8 * hi);
+    }
+
+    // ---- staging: 512 16-byte pieces of K and of V^T per tile, two of each per thread ------------------------------------------------------
+    const int srow = tid >> 3;
+    const int schunk = (tid & 7) ^ ((srow >> 1) & 7);
+    const int wave_s = __builtin_amdgcn_readfirstlane(L.wave);
+    const buf_rsrc_t k_rsrc = make_buf_rsrc(Kg, (unsigned)S * FA_D * 2);
+    const buf_rsrc_t v_rsrc = make_buf_rsrc(Vg, (unsigned)p.Spad * FA_D * 2);
+    const unsigned k_voff = srow * (FA_D * 2) + schunk * 16;
+    const unsigned v_voff = (unsigned)srow * p.Spad * 2 + schunk * 16;
+    auto stage_k = [&](int j, int slot) {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps)
+            bglds16(k_rsrc, k_voff + ps * (NW * 8) * (FA_D * 2), j * (FA_KVBLK * FA_D * 2), kring + slot * FA_TILE + wave_s * 1024 + ps * (NW * 1024));
+    };
+    auto stage_v = [&](int j, int slot) {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps)
+            bglds16(v_rsrc, v_voff + ps * (NW * 8) * (unsigned)p.Spad * 2, j * (FA_KVBLK * 2), vring + slot * FA_TILE + wave_s * 1024 + ps * (NW * 1024));
+    };
+
+    const int nkv = (S + FA_KVBLK - 1) / FA_KVBLK;
+    const bool ragged = (S & (FA_KVBLK - 1)) != 0;
+    f32x16 o[2][2];
+    float l_run[2];
+    auto reset_acc = [&]() {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            l_run[b] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o[b][0][i] = 0.f; o[b][1][i] = 0.f; }
+        }
+    };
+    // scores of half t of tile j: sc[r] = score(q = l32, key = 64j + 32t + 16(r>>3) + 8hi + (r&7)); keys >= S -> -inf
+    auto mask_half = [&](f32x16 (&sc)[2], int j, int t) {
+        const int kb = j * FA_KVBLK + 32 * t + 8 * hi;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (kb + 16 * (r >> 3) + (r & 7) >= S) { sc[0][r] = -INFINITY; sc[1][r] = -INFINITY; }
+    };
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    // =========================================== optimistic sweep (shift 0) ==================================================================
+    bool need_redo = true;
+    if (nkv >= 3) {
+        reset_acc();
+        stage_k(0, 0); stage_k(1, 1); stage_k(2, 2); stage_v(0, 0); stage_v(1, 1);
+        drain_and_barrier();
+        f32x16 scA[2], scB[2];
+        u32x4 pfA[2][2], pfB[2][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pfB[b][s2][e] = 0u;
+        // prologue: scores of tile 0, keys 0..31
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 kf = *(const bf16x8*)(kring + L.koff[ks]);
+            scA[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][ks], ks == 0 ? zero : scA[0], 0, 0, 0);
+            scA[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][ks], ks == 0 ? zero : scA[1], 0, 0, 0);
+        }
+        float ps[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+        // soft-max of two scores (elements 2e, 2e+1) of block b of a half: exp2, packed bf16 pair, row-sum update
+        auto sm2 = [&](const f32x16& sc, u32x4 (&pf)[2], int b, int e) {
+            const unsigned w = fa_exp_pair<DOT2>(sc[2 * e], sc[2 * e + 1], ps[b][0], ps[b][1]);
+            asm volatile("" : "+v"(ps[b][0]), "+v"(ps[b][1]));
+            pf[e >> 2][e & 3] = w;
+        };
+        // slot = 8 MFMAs from 4 fragments (each feeds both query blocks) + the soft-max of 16 scores of block `smb` of `sc_sm`
+        auto qk_slot = [&](const char* kbase, f32x16 (&sc_out)[2], const f32x16 (&sc_sm)[2], u32x4 (&pf_sm)[2][2], auto SMB) {
+            constexpr int smb = decltype(SMB)::value;
+            bf16x8 kf = *(const bf16x8*)(kbase + L.koff[0]);
+            static_for<4>([&](auto KS) {
+                constexpr int ks = decltype(KS)::value;
+                bf16x8 nf = kf;
+                if constexpr (ks < 3) nf = *(const bf16x8*)(kbase + L.koff[ks + 1]);
+                sc_out[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][ks], ks == 0 ? zero : sc_out[0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                sm2(sc_sm[smb], pf_sm[smb], smb, 2 * ks);
+                __builtin_amdgcn_sched_barrier(0);
+                sc_out[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][ks], ks == 0 ? zero : sc_out[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                sm2(sc_sm[smb], pf_sm[smb], smb, 2 * ks + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                kf = nf;
+            });
+        };
+        auto pv_slot = [&](const char* vbase, int t, const u32x4 (&pf_in)[2][2], const f32x16 (&sc_sm)[2], u32x4 (&pf_sm)[2][2], auto SMB) {
+            constexpr int smb = decltype(SMB)::value;
+            bf16x8 vf = *(const bf16x8*)(vbase + voff[t][0]);
+            static_for<4>([&](auto G) {
+                constexpr int g = decltype(G)::value;          // fragment g: s2 = g >> 1, dt = g & 1
+                constexpr int s2 = g >> 1, dt = g & 1;
+                bf16x8 nf = vf;
+                if constexpr (g < 3) nf = *(const bf16x8*)(vbase + ((g + 1) & 1) * 4096 + voff[t][(g + 1) >> 1]);
+                o[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pf_in[0][s2]), o[0][dt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                sm2(sc_sm[smb], pf_sm[smb], smb, 2 * g);
+                __builtin_amdgcn_sched_barrier(0);
+                o[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pf_in[1][s2]), o[1][dt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                sm2(sc_sm[smb], pf_sm[smb], smb, 2 * g + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                vf = nf;
+            });
+        };
+        int sk = 0;                                            // ring slot of K(j) = V(j); K(j+1): sk1; V(j-1), K(j+2): sk2
+        for (int j = 0; j < nkv; ++j) {
+            const int sk1 = sk == 2 ? 0 : sk + 1, sk2 = sk == 0 ? 2 : sk - 1;
+            const bool last = j == nkv - 1;
+            if (last && ragged) mask_half(scA, j, 0);
+            qk_slot(kring + sk * FA_TILE + 4096, scB, scA, pfA, ic<0>{});                                   // slot 1
+            pv_slot(vring + (j == 0 ? sk : sk2) * FA_TILE, 1, pfB, scA, pfA, ic<1>{});                    // slot 2 (j = 0: pfB = 0, any finite V)
+            if (last && ragged) mask_half(scB, j, 1);
+            qk_slot(kring + sk1 * FA_TILE, scA, scB, pfB, ic<0>{});                                         // slot 3 (past the end: unused scores)
+            pv_slot(vring + sk * FA_TILE, 0, pfA, scB, pfB, ic<1>{});                                       // slot 4
+            drain_and_barrier();
+            if (j + 3 < nkv) stage_k(j + 3, sk);
+            if (j + 2 < nkv) stage_v(j + 2, sk2);
+            sk = sk1;
+        }
+        // epilogue: P·V of the last half (keys 32..63 of tile nkv-1; its V sits in the slot before `sk`)
+        {
+            const char* vbase = vring + (sk == 0 ? 2 : sk - 1) * FA_TILE;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int s2 = g >> 1, dt = g & 1;
+                const bf16x8 vf = *(const bf16x8*)(vbase + dt * 4096 + voff[1][s2]);
+                o[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pfB[0][s2]), o[0][dt], 0, 0, 0);
+                o[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pfB[1][s2]), o[1][dt], 0, 0, 0);
+            }
+        }
+        l_run[0] = ps[0][0] + ps[0][1];
+        l_run[1] = ps[1][0] + ps[1][1];
+        // validity of the finished rows (see the tile-pair kernel): finite sums not below 2^-100, finite accumulators
+        bool ok = true;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const float l_tot = l_run[b] + __shfl_xor(l_run[b], 32, 64);
+            float chk = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { chk = fmaf(o[b][0][i], 0.f, chk); chk = fmaf(o[b][1][i], 0.f, chk); }
+            ok = ok && (l_tot >= FA_SUM_FLOOR && l_tot < INFINITY && chk == 0.f);
+        }
+        const bool mine = __all(ok) != 0;
+        block_barrier();
+        if (L.lane == 0) votes[L.wave] = mine ? 1.f : 0.f;
+        block_barrier();
+        bool all_ok = true;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) all_ok = all_ok && (votes[w] != 0.f);
+        need_redo = !all_ok;
+    }
+
+    // =========================================== conservative sweep (classic online soft-max) ==============================================
+    if (need_redo) {
+        reset_acc();
+        float m_run[2] = {-INFINITY, -INFINITY};
+        block_barrier();
+        stage_k(0, 0); stage_v(0, 0);
+        drain_and_barrier();
+        for (int j = 0; j < nkv; ++j) {
+            const int cur = j & 1;
+            if (j + 1 < nkv) { stage_k(j + 1, cur ^ 1); stage_v(j + 1, cur ^ 1); }
+            const char* kbase = kring + cur * FA_TILE;
+            const char* vbase = vring + cur * FA_TILE;
+            f32x16 sc[2][2];                                  // [half t][block b]
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 kf = *(const bf16x8*)(kbase + t * 4096 + L.koff[ks]);
+                    sc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][ks], ks == 0 ? zero : sc[t][0], 0, 0, 0);
+                    sc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][ks], ks == 0 ? zero : sc[t][1], 0, 0, 0);
+                }
+            if (j == nkv - 1 && ragged) { mask_half(sc[0], j, 0); mask_half(sc[1], j, 1); }
+            u32x4 pf[2][2][2];                                // [half t][block b][slab s2]
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                float mx = sc[0][b][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[0][b][r]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[1][b][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = fmaxf(m_run[b], mx);      // finite from tile 0 on: every tile holds at least one unmasked key
+                const float alpha = __builtin_amdgcn_exp2f(m_run[b] - m_new);   // 0 on the first tile
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { o[b][0][i] *= alpha; o[b][1][i] *= alpha; }
+                l_run[b] *= alpha;
+                m_run[b] = m_new;
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        pf[t][b][e >> 2][e & 3] = fa_exp_pair<DOT2>(sc[t][b][2 * e] - m_new, sc[t][b][2 * e + 1] - m_new, s0, s1);
+                l_run[b] += s0 + s1;
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int s2 = g >> 1, dt = g & 1;
+                    const bf16x8 vf = *(const bf16x8*)(vbase + dt * 4096 + voff[t][s2]);
+                    o[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pf[t][0][s2]), o[0][dt], 0, 0, 0);
+                    o[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pf[t][1][s2]), o[1][dt], 0, 0, 0);
+                }
+            drain_and_barrier();
+        }
+    }
+    fa_store<WIDE_STORE>(o[0], l_run[0], p, bh, qrow[0], hi);
+    fa_store<WIDE_STORE>(o[1], l_run[1], p, bh, qrow[1], hi);
+}
+
 }  // namespace aether
 
 using namespace aether;
@@ -831,7 +1132,21 @@ extern "C" int aether_flash_attn_fwd(const void* Qh, const void* Kh, const void*
     hipStream_t s = (hipStream_t)stream;
     const bool wide = (flags & AETHER_GEMM_WIDE_STORE) != 0;
     dim3 grid(p.nwg), block(512);
-    if (flags & AETHER_ATTN_PIPELINED) {
+    if ((flags & AETHER_ATTN_ROWS64) && !(flags & (AETHER_ATTN_PIPELINED | AETHER_ATTN_EXACT_MAX))) {
+        const bool dot2 = (flags & AETHER_ATTN_DOT2_SUM) != 0;
+        if (flags & AETHER_ATTN_WG512) {
+            p.nqb = (S + 511) / 512;
+            p.nwg = p.nqb * B * H;
+            const dim3 g2(p.nwg), b2(512);
+            if (wide && dot2) hipLaunchKernelGGL((flash_attn_rows64_kernel<true, true, 8>), g2, b2, 0, s, p);
+            else if (wide) hipLaunchKernelGGL((flash_attn_rows64_kernel<true, false, 8>), g2, b2, 0, s, p);
+            else if (dot2) hipLaunchKernelGGL((flash_attn_rows64_kernel<false, true, 8>), g2, b2, 0, s, p);
+            else hipLaunchKernelGGL((flash_attn_rows64_kernel<false, false, 8>), g2, b2, 0, s, p);
+        } else if (wide && dot2) hipLaunchKernelGGL((flash_attn_rows64_kernel<true, true, 4>), grid, dim3(256), 0, s, p);
+        else if (wide) hipLaunchKernelGGL((flash_attn_rows64_kernel<true, false, 4>), grid, dim3(256), 0, s, p);
+        else if (dot2) hipLaunchKernelGGL((flash_attn_rows64_kernel<false, true, 4>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((flash_attn_rows64_kernel<false, false, 4>), grid, dim3(256), 0, s, p);
+    } else if (flags & AETHER_ATTN_PIPELINED) {
         if (wide) hipLaunchKernelGGL((flash_attn_swp_kernel<true>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((flash_attn_swp_kernel<false>), grid, block, 0, s, p);
     } else {
@@ -843,14 +1158,19 @@ extern "C" int aether_flash_attn_fwd(const void* Qh, const void* Kh, const void*
         const int rest = p.nwg - full;
         if (full > 0) {
             p.nwg = full; p.wg_first = 0;
-            if (flags & AETHER_ATTN_PAIR_PIPELINE) {
-                if (wide) hipLaunchKernelGGL((flash_attn_fwd_kernel<true, 8, 1, 2>), dim3(full), dim3(512), 0, s, p);
-                else hipLaunchKernelGGL((flash_attn_fwd_kernel<false, 8, 1, 2>), dim3(full), dim3(512), 0, s, p);
-            } else if (flags & AETHER_ATTN_INTERLEAVE) {
-                if (wide) hipLaunchKernelGGL((flash_attn_fwd_kernel<true, 8, 1, 1>), dim3(full), dim3(512), 0, s, p);
-                else hipLaunchKernelGGL((flash_attn_fwd_kernel<false, 8, 1, 1>), dim3(full), dim3(512), 0, s, p);
-            } else if (wide) hipLaunchKernelGGL((flash_attn_fwd_kernel<true, 8>), dim3(full), dim3(512), 0, s, p);
-            else hipLaunchKernelGGL((flash_attn_fwd_kernel<false, 8>), dim3(full), dim3(512), 0, s, p);
+            const int ilv = (flags & AETHER_ATTN_EXACT_MAX) ? 0 : (flags & AETHER_ATTN_PAIR_PIPELINE) ? 2 : (flags & AETHER_ATTN_INTERLEAVE) ? 1 : 0;
+            const bool dot2 = (flags & AETHER_ATTN_DOT2_SUM) != 0;
+            const bool qreg = (flags & AETHER_ATTN_QREG) != 0 && ilv == 2;
+            auto launch = [&](auto W, auto I, auto D) {
+                constexpr int ILV_ = decltype(I)::value;
+                if constexpr (ILV_ == 2) {
+                    if (qreg) { hipLaunchKernelGGL((flash_attn_fwd_kernel<decltype(W)::value, 8, 1, 2, decltype(D)::value, true>), dim3(full), dim3(512), 0, s, p); return; }
+                }
+                hipLaunchKernelGGL((flash_attn_fwd_kernel<decltype(W)::value, 8, 1, ILV_, decltype(D)::value>), dim3(full), dim3(512), 0, s, p);
+            };
+            auto by_dot2 = [&](auto W, auto I) { if (dot2) launch(W, I, std::true_type{}); else launch(W, I, std::false_type{}); };
+            auto by_ilv = [&](auto W) { if (ilv == 2) by_dot2(W, ic<2>{}); else if (ilv == 1) by_dot2(W, ic<1>{}); else by_dot2(W, ic<0>{}); };
+            if (wide) by_ilv(std::true_type{}); else by_ilv(std::false_type{});
         }
         if (rest > 0) {
             p.nqb *= 2; p.nwg = 2 * rest; p.wg_first = 2 * full;

@@ -5,6 +5,7 @@
 // ff.net.0.proj (+GELU-tanh), ff.net.2 (+gate·x+residual), patch_embed.proj/text_proj, proj_out.
 // Kernel: gemm_kernel.hpp, 256x256x64 tile (2x4 waves, 128x64 per wave).
 #include "gemm4_kernel.hpp"
+#include "gemm_persist_kernel.hpp"
 #include "../../include/aether_hip.h"
 
 using namespace aether;
@@ -111,8 +112,29 @@ extern "C" int aether_gemm_bf16(const void* A, int lda, const void* W, int ldw, 
     if (ks < 2 || splitk_ws == nullptr || full == 0 || (((uintptr_t)splitk_ws) & 15) ||
         (size_t)ks * rest * 256 * 256 * sizeof(float) > splitk_ws_bytes)
         ks = 1;
-    p.ntile_launch = (ks > 1) ? full : tiles;
     const bool four_wave = (flags & AETHER_GEMM_4WAVE) != 0;
+    const bool persistent = (flags & AETHER_GEMM_PERSISTENT) && p.stagger == 1 && !four_wave && tiles > NCU;
+    if (persistent) {
+        // persistent grid (gemm_persist_kernel.hpp).  Short last round (split-K tail available): 256 workgroups stream the FULL rounds,
+        // the tail launch below takes the rest.  Otherwise G = ceil(tiles / rounds) workgroups own whole tiles and there is no tail.
+        p.ntile_launch = (ks > 1) ? full : tiles; p.ksplit = 1;
+        const int rounds = (p.ntile_launch + NCU - 1) / NCU;
+        const int G = 8 * (((p.ntile_launch + 7) / 8 + rounds - 1) / rounds);       // per XCD: ceil(band / rounds) workgroups; <= 256
+#define LAUNCH_P(E)                                                                                                       \
+        do {                                                                                                              \
+            if (wide) hipLaunchKernelGGL((gemm_bf16_persistent_kernel<E, true>), dim3(G), block, 0, s, p);                 \
+            else hipLaunchKernelGGL((gemm_bf16_persistent_kernel<E, false>), dim3(G), block, 0, s, p);                     \
+        } while (0)
+        switch (epilogue) {
+            case EPI_BIAS: LAUNCH_P(EPI_BIAS); break;
+            case EPI_BIAS_GELU: LAUNCH_P(EPI_BIAS_GELU); break;
+            default: LAUNCH_P(EPI_BIAS_GATE_RES); break;
+        }
+#undef LAUNCH_P
+        rc = aether_check_launch("gemm_bf16 (persistent)");
+        if (rc || ks == 1) return rc;
+    }
+    p.ntile_launch = (ks > 1) ? full : tiles;
 #define LAUNCH(E)                                                                                                        \
     do {                                                                                                                 \
         dim3 grid(p.ntile_launch * p.ksplit);                                                                            \
@@ -128,10 +150,12 @@ extern "C" int aether_gemm_bf16(const void* A, int lda, const void* W, int ldw, 
         case EPI_BIAS_GELU: LAUNCH(EPI_BIAS_GELU); break;   \
         default: LAUNCH(EPI_BIAS_GATE_RES); break;          \
     }
-    p.ksplit = 1;
-    LAUNCH_EPI();
-    rc = aether_check_launch("gemm_bf16");
-    if (rc || ks == 1) return rc;
+    if (!persistent) {
+        p.ksplit = 1;
+        LAUNCH_EPI();
+        rc = aether_check_launch("gemm_bf16");
+        if (rc || ks == 1) return rc;
+    }
     p.tile_base = full; p.ntile_launch = rest; p.ksplit = ks; p.part = splitk_ws; p.part_tiled = 1;
     LAUNCH_EPI();
     rc = aether_check_launch("gemm_bf16 (tail)");

@@ -66,6 +66,117 @@ AE_DEV void gemm_tile_coords(int wgid, int tiles_m, int tiles_n, int& tile_m, in
     tile_n = in_group / gsz;
 }
 
+// ---- fused epilogue of one output tile (shared by the one-tile-per-workgroup kernel below and the persistent kernel) -------------------
+// acc[mt][nt][r] = C[m][n], m = m0 + (wm*MT + mt)*32 + l32,  n = n0 + (wn*NT + nt)*32 + 8*(r>>2) + 4*hi + (r&3)
+template <int WM, int WN, int MT, int NT, int EPI, bool WIDE_STORE>
+AE_DEV void gemm_epilogue(const GemmArgs& p, const f32x16 (&acc)[MT][NT], int m0, int n0, int wm, int wn, int l32, int hi) {
+    // Every operand of the epilogue is fetched BEFORE it is used, in batches: the bias of the wave's column groups once, then per
+    // 32-row block its gate vectors and residual rows (16 loads in flight).  (Round 1 issued each of the 12 loads of a 32x32
+    // sub-tile behind its own branch, every one followed by s_waitcnt vmcnt(0): 96 dependent round trips ≈ 15 µs per tile — 18 %
+    // of the out-projection, 5 % of the other GEMMs.)  Rows / column groups outside the problem load from clamped addresses and
+    // are not stored.
+    const bool has_bias = p.bias != nullptr;
+    const bool has_gate = (EPI == EPI_BIAS_GATE_RES) && p.gate_vid != nullptr;
+    const bool has_res = (EPI == EPI_BIAS_GATE_RES) && p.R != nullptr;
+    int ncol[NT];
+    bool n_ok[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int nbase = n0 + (wn * NT + nt) * 32;   // N % 32 == 0: a 32-column group is all in or all out (wave-uniform)
+        n_ok[nt] = nbase < p.N;
+        ncol[nt] = n_ok[nt] ? nbase : 0;
+    }
+    f32x4 bv[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bv[nt][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (has_bias) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bv[nt][g] = *(const f32x4*)(p.bias + ncol[nt] + 8 * g + 4 * hi);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + (wm * MT + mt) * 32 + l32;
+        const bool m_ok = m < p.M;
+        const int mm = m_ok ? m : p.M - 1;
+        f32x4 gv[NT][4];
+        u16x4 rv[NT][4];
+        {
+            const int b = has_gate ? mm / p.rows_per_batch : 0;
+            const int t = mm - b * p.rows_per_batch;
+            const float* gate = has_gate ? (t < p.n_text ? p.gate_txt : p.gate_vid) + (size_t)b * p.gate_bstride : nullptr;
+            auto load_gate = [&]() {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) gv[nt][g] = *(const f32x4*)(gate + ncol[nt] + 8 * g + 4 * hi);
+            };
+            auto load_res = [&]() {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) rv[nt][g] = *(const u16x4*)(p.R + (size_t)mm * p.ldr + ncol[nt] + 8 * g + 4 * hi);
+            };
+            // one basic block per combination: the 16 loads of a row block stay in flight together (a block boundary between the two
+            // groups makes the compiler drain the first before issuing the second)
+            if (has_gate && has_res) { load_res(); load_gate(); }
+            else if (has_gate) load_gate();
+            else if (has_res) load_res();
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (!n_ok[nt]) continue;                      // wave-uniform
+            const int nbase = ncol[nt];
+            unsigned pk[4][2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = acc[mt][nt][4 * g + c] + bv[nt][g][c];
+                if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = gelu_tanh(v[c]);
+                }
+                if (EPI == EPI_BIAS_GATE_RES) {
+                    if (has_gate) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] *= gv[nt][g][c];
+                    }
+                    if (has_res) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] += bf16_bits_to_f32(rv[nt][g][c]);
+                    }
+                }
+                pk[g][0] = pack_bf16x2(v[0], v[1]);
+                pk[g][1] = pack_bf16x2(v[2], v[3]);
+            }
+            if (WIDE_STORE) {
+                // half-wave exchange: lanes 0-31 end with columns 8g..8g+7, lanes 32-63 with 8(g+1)..8(g+1)+7
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    auto r0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
+                    auto r1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
+                    if (m_ok) {
+                        uint4 o = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                        *(uint4*)(p.C + (size_t)m * p.ldc + nbase + 8 * g + 8 * hi) = o;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (m_ok) {
+                        uint2 o = make_uint2(pk[g][0], pk[g][1]);
+                        *(uint2*)(p.C + (size_t)m * p.ldc + nbase + 8 * g + 4 * hi) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <int WM, int WN, int MT, int NT, int EPI, bool WIDE_STORE, bool GATHER>
 __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
     static_assert(WM * WN == 8, "8 wavefronts per workgroup");
@@ -427,111 +538,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
         }
         return;
     }
-    // Every operand of the epilogue is fetched BEFORE it is used, in batches: the bias of the wave's column groups once, then per
-    // 32-row block its gate vectors and residual rows (16 loads in flight).  (Round 1 issued each of the 12 loads of a 32x32
-    // sub-tile behind its own branch, every one followed by s_waitcnt vmcnt(0): 96 dependent round trips ≈ 15 µs per tile — 18 %
-    // of the out-projection, 5 % of the other GEMMs.)  Rows / column groups outside the problem load from clamped addresses and
-    // are not stored.
-    const bool has_bias = p.bias != nullptr;
-    const bool has_gate = (EPI == EPI_BIAS_GATE_RES) && p.gate_vid != nullptr;
-    const bool has_res = (EPI == EPI_BIAS_GATE_RES) && p.R != nullptr;
-    int ncol[NT];
-    bool n_ok[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int nbase = n0 + (wn * NT + nt) * 32;   // N % 32 == 0: a 32-column group is all in or all out (wave-uniform)
-        n_ok[nt] = nbase < p.N;
-        ncol[nt] = n_ok[nt] ? nbase : 0;
-    }
-    f32x4 bv[NT][4];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bv[nt][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (has_bias) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) bv[nt][g] = *(const f32x4*)(p.bias + ncol[nt] + 8 * g + 4 * hi);
-    }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int m = m0 + (wm * MT + mt) * 32 + l32;
-        const bool m_ok = m < p.M;
-        const int mm = m_ok ? m : p.M - 1;
-        f32x4 gv[NT][4];
-        u16x4 rv[NT][4];
-        {
-            const int b = has_gate ? mm / p.rows_per_batch : 0;
-            const int t = mm - b * p.rows_per_batch;
-            const float* gate = has_gate ? (t < p.n_text ? p.gate_txt : p.gate_vid) + (size_t)b * p.gate_bstride : nullptr;
-            auto load_gate = [&]() {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) gv[nt][g] = *(const f32x4*)(gate + ncol[nt] + 8 * g + 4 * hi);
-            };
-            auto load_res = [&]() {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) rv[nt][g] = *(const u16x4*)(p.R + (size_t)mm * p.ldr + ncol[nt] + 8 * g + 4 * hi);
-            };
-            // one basic block per combination: the 16 loads of a row block stay in flight together (a block boundary between the two
-            // groups makes the compiler drain the first before issuing the second)
-            if (has_gate && has_res) { load_res(); load_gate(); }
-            else if (has_gate) load_gate();
-            else if (has_res) load_res();
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            if (!n_ok[nt]) continue;                      // wave-uniform
-            const int nbase = ncol[nt];
-            unsigned pk[4][2];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float v[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = acc[mt][nt][4 * g + c] + bv[nt][g][c];
-                if (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = gelu_tanh(v[c]);
-                }
-                if (EPI == EPI_BIAS_GATE_RES) {
-                    if (has_gate) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) v[c] *= gv[nt][g][c];
-                    }
-                    if (has_res) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) v[c] += bf16_bits_to_f32(rv[nt][g][c]);
-                    }
-                }
-                pk[g][0] = pack_bf16x2(v[0], v[1]);
-                pk[g][1] = pack_bf16x2(v[2], v[3]);
-            }
-            if (WIDE_STORE) {
-                // half-wave exchange: lanes 0-31 end with columns 8g..8g+7, lanes 32-63 with 8(g+1)..8(g+1)+7
-#pragma unroll
-                for (int g = 0; g < 4; g += 2) {
-                    auto r0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
-                    auto r1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
-                    if (m_ok) {
-                        uint4 o = make_uint4(r0[0], r1[0], r0[1], r1[1]);
-                        *(uint4*)(p.C + (size_t)m * p.ldc + nbase + 8 * g + 8 * hi) = o;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    if (m_ok) {
-                        uint2 o = make_uint2(pk[g][0], pk[g][1]);
-                        *(uint2*)(p.C + (size_t)m * p.ldc + nbase + 8 * g + 4 * hi) = o;
-                    }
-                }
-            }
-        }
-    }
+    gemm_epilogue<WM, WN, MT, NT, EPI, WIDE_STORE>(p, acc, m0, n0, wm, wn, l32, hi);
 }
 
 }  // namespace aether

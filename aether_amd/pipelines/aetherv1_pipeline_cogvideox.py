@@ -205,6 +205,9 @@ class AetherV1PipelineCogVideoX(_PipelineBase):
     # Extension (not in the reference): leave rgb / disparity / raymap as float32 torch tensors on the execution device — same
     # values, no D2H copy — for callers that keep working on the GPU (sliding-window gather + merge, aether_amd/windows.py).
     keep_outputs_on_device = False
+    # Extension: run the element-wise tail of every denoise step (P:877-916) as one HIP kernel (aether_dpm_step) when the scheduler is this
+    # repo's CogVideoXDPMScheduler on an MI355X.  Bit-identical to the PyTorch sequence; False keeps the reference's op-by-op form.
+    fuse_step_tail = True
 
     def __init__(self, tokenizer, text_encoder, vae, scheduler, transformer, empty_prompt_embeds: Optional[torch.Tensor] = None):
         super().__init__(tokenizer=tokenizer, text_encoder=text_encoder, vae=vae, scheduler=scheduler, transformer=transformer)
@@ -418,9 +421,10 @@ class AetherV1PipelineCogVideoX(_PipelineBase):
         self._cfg_group, self._cfg_rank = None, 0
 
     def _gather_pair(self, x: torch.Tensor) -> torch.Tensor:
-        """[1, ...] on each rank of the pair -> [2, ...] in group-rank order on both."""
+        """[1, ...] on each rank of the pair -> [2, ...] in group-rank order on both (one part per rank of the group: a one-rank group —
+        the RCCL configuration a one-GPU box can exercise — returns its own part)."""
         import torch.distributed as dist
-        parts = [torch.empty_like(x, memory_format=torch.contiguous_format) for _ in range(2)]
+        parts = [torch.empty_like(x, memory_format=torch.contiguous_format) for _ in range(dist.get_world_size(self._cfg_group))]
         dist.all_gather(parts, x.contiguous(), group=self._cfg_group)
         return torch.cat(parts)
 
@@ -490,6 +494,10 @@ class AetherV1PipelineCogVideoX(_PipelineBase):
         if split:
             latent_condition = latent_condition[self._cfg_rank:self._cfg_rank + 1]
         text = prompt_embeds.repeat(2 if (do_cfg and not split) else 1, 1, 1)
+        # the element-wise tail of a step as one HIP kernel: this repo's DPM scheduler, v-prediction, bf16 latents on an MI355X, and a
+        # guidance scale that is not a per-sample tensor; anything else takes the reference's PyTorch sequence
+        fused_tail = (self.fuse_step_tail and dpm and hasattr(self.scheduler, "step_fused") and latents.is_cuda and latents.dtype == torch.bfloat16
+                      and getattr(self.scheduler.config, "prediction_type", None) == "v_prediction" and latents.shape[0] == 1)
 
         with self.progress_bar(total=num_inference_steps) as bar:
             old_x0 = None
@@ -505,23 +513,30 @@ class AetherV1PipelineCogVideoX(_PipelineBase):
                                               attention_kwargs=attention_kwargs, return_dict=False)[0]
                 if split:
                     noise_pred = self._gather_pair(noise_pred)                                   # (unconditional, conditional)
-                noise_pred = noise_pred.float()
                 if use_dynamic_cfg:
                     # the reference feeds the raw timestep value (999 ... 19) here, literally (P:880-893)
                     frac = (num_inference_steps - t_host[i]) / num_inference_steps
                     self._guidance_scale = 1 + guidance_scale * ((1 - math.cos(math.pi * frac ** 5.0)) / 2)
-                if do_cfg:
-                    uncond, cond = noise_pred.chunk(2)
-                    noise_pred = uncond + self.guidance_scale * (cond - uncond)
-                if not dpm:
-                    latents = self.scheduler.step(noise_pred, t, latents, **extra_step_kwargs, return_dict=False)[0]
+                if fused_tail and noise_pred.dtype == torch.bfloat16:
+                    # P:877-916 (fp32 cast, guidance combine, scheduler.step, cast back) as ONE kernel — bit-identical to the sequence below
+                    latents, old_x0 = self.scheduler.step_fused(noise_pred, old_x0, t_host[i], t_host[i - 1] if i > 0 else None, latents,
+                                                                guidance_scale=self.guidance_scale if do_cfg else None,
+                                                                generator=extra_step_kwargs.get("generator"))
                 else:
-                    latents, old_x0 = self.scheduler.step(noise_pred, old_x0, t, timesteps[i - 1] if i > 0 else None, latents,
-                                                          **extra_step_kwargs, return_dict=False)
-                latents = latents.to(prompt_embeds.dtype)
+                    noise_pred = noise_pred.float()
+                    if do_cfg:
+                        uncond, cond = noise_pred.chunk(2)
+                        noise_pred = uncond + self.guidance_scale * (cond - uncond)
+                    if not dpm:
+                        latents = self.scheduler.step(noise_pred, t, latents, **extra_step_kwargs, return_dict=False)[0]
+                    else:
+                        latents, old_x0 = self.scheduler.step(noise_pred, old_x0, t, timesteps[i - 1] if i > 0 else None, latents,
+                                                              **extra_step_kwargs, return_dict=False)
+                    latents = latents.to(prompt_embeds.dtype)
                 if i == len(timesteps) - 1 or ((i + 1) > n_warm and (i + 1) % self.scheduler.order == 0):
                     bar.update()
         self._current_timestep = None
+        self._final_latents = latents             # extension: what the loop ended on (parity tests compare it; P:921)
 
         nz = self.vae.config.latent_channels
         rgb_latents, disparity_latents, camera_latents = latents[:, :, :nz], latents[:, :, nz:2 * nz], latents[:, :, 2 * nz:]

@@ -113,6 +113,54 @@ class CogVideoXDPMScheduler:
     def _lambda(a):
         return ((a / (1 - a)) ** 0.5).log()
 
+    def _coefficients(self, timestep, timestep_back, second_order_possible: bool):
+        """The float64 host scalars of one update (same expressions, same order as `step`)."""
+        c = self.config
+        t = int(timestep)
+        prev_t = t - c.num_train_timesteps // self.num_inference_steps
+        a_t = self.alphas_cumprod[t]
+        a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
+        lamb, lamb_next = self._lambda(a_t), self._lambda(a_prev)
+        h = lamb_next - lamb
+        out = dict(a_sqrt=a_t ** 0.5, b_sqrt=(1 - a_t) ** 0.5, m1=((1 - a_prev) / (1 - a_t)) ** 0.5 * (-h).exp(),
+                   m2=(-2 * h).expm1() * a_prev ** 0.5, m_noise=(1 - a_prev) ** 0.5 * (1 - (-2 * h).exp()) ** 0.5,
+                   second=bool(second_order_possible and prev_t >= 0))
+        if out["second"]:
+            r = (lamb - self._lambda(self.alphas_cumprod[int(timestep_back)])) / h
+            out["m3"], out["m4"] = 1 + 1 / (2 * r), 1 / (2 * r)
+        return out
+
+    def step_fused(self, model_output, old_pred_original_sample, timestep, timestep_back, sample, guidance_scale=None, generator=None):
+        """The element-wise tail of one denoise step as ONE HIP kernel (`aether_dpm_step`, csrc/sampler.hip): what the reference's
+        loop does between the transformer call and the next iteration (P:876-916) — `noise_pred.float()`, the classifier-free-guidance
+        combine when `model_output` holds (unconditional, conditional), `step(...)` and the cast back to the latents' dtype.
+        model_output: the transformer's bf16 output [1 or 2, ...]; sample: bf16 latents [1, ...].  Returns (latents bf16, x0 fp32),
+        BIT-IDENTICAL to the PyTorch sequence (tests/test_kernels_gpu.py::test_dpm_step_fused_is_bit_identical); the random draws are
+        made here with torch, in `step`'s order (one draw, or two when the second-order form applies — the first one is then unused,
+        exactly as in diffusers).  v-prediction on a CUDA device only; callers fall back to `step` otherwise."""
+        from . import _lib
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
+        if self.config.prediction_type != "v_prediction" or not sample.is_cuda or sample.dtype != torch.bfloat16 or model_output.dtype != torch.bfloat16:
+            raise NotImplementedError("step_fused: v-prediction, bf16 CUDA tensors only")
+        nb = model_output.shape[0]
+        if sample.shape[0] != 1 or nb not in (1, 2) or (nb == 2) != (guidance_scale is not None):
+            raise ValueError("step_fused: sample must be [1, ...], model_output [1, ...] or [2, ...] with a guidance scale")
+        k = self._coefficients(timestep, timestep_back, old_pred_original_sample is not None)
+        noise = randn_tensor(sample.shape, generator=generator, device=sample.device, dtype=sample.dtype)
+        if k["second"]:
+            noise = randn_tensor(sample.shape, generator=generator, device=sample.device, dtype=sample.dtype)
+        mo, smp = model_output.contiguous(), sample.contiguous()
+        old = old_pred_original_sample.contiguous() if k["second"] else None
+        x0 = torch.empty(sample.shape, dtype=torch.float32, device=sample.device)
+        prev = torch.empty_like(smp)
+        f = lambda v: float(torch.as_tensor(v, dtype=torch.float64).to(torch.float32))  # noqa: E731  (the rounding PyTorch applies to a scalar operand)
+        _lib.check(_lib.load().aether_dpm_step(mo.data_ptr(), nb, f(guidance_scale if nb == 2 else 0.0), smp.data_ptr(), _lib.ptr(old), noise.data_ptr(),
+                                               f(k["a_sqrt"]), f(k["b_sqrt"]), f(k["m1"]), f(k["m2"]), f(k["m_noise"]), f(k.get("m3", 0.0)),
+                                               f(k.get("m4", 0.0)), x0.data_ptr(), None, prev.data_ptr(), smp.numel(), _lib.current_stream()),
+                   "aether_dpm_step")
+        return prev, x0
+
     def step(self, model_output, old_pred_original_sample, timestep, timestep_back, sample, eta: float = 0.0,
              use_clipped_model_output: bool = False, generator=None, variance_noise=None, return_dict: bool = False):
         if self.num_inference_steps is None:

@@ -309,10 +309,11 @@ class AetherVAE:
         key = (decode, T, H, W, bool(self.use_tiling))
         ent = self._graphs.get(key)
         if ent is None:
-            # first call of this geometry: eager (it also zeroes / fills what the pool needs); the second one is captured
-            self._graphs[key] = "seen"
+            # first call of this geometry: eager (it also zeroes / fills what the pool needs); the second one is captured — but only
+            # after the eager call SUCCEEDED (a failed first call must not let the next one capture the pool's one-time set-up)
             out = torch.empty(oshape, dtype=torch.bfloat16, device=self.device)
             call(src, out)
+            self._graphs[key] = "seen"
             return out
         if ent == "seen":
             s_in, s_out = torch.empty_like(src), torch.empty(oshape, dtype=torch.bfloat16, device=self.device)

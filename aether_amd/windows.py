@@ -32,6 +32,9 @@ def get_window_starts(total_frames: int, sliding_window_size: int, temporal_stri
 
 @dataclass
 class WindowResult:
+    """One window's outputs.  Contract: `rgb` / `disparity` are numpy float32 arrays, EXCEPT after `run_windows(keep_on_device=True)`
+    on a CUDA gather device, where they are float32 torch tensors on that device (views of the gathered buffers, for
+    `blend_and_merge_window_results(..., device=)`); `raymap` is always numpy."""
     start: int
     rgb: np.ndarray         # [F, H, W, 3] float32 (a torch tensor after run_windows(keep_on_device=True))
     disparity: np.ndarray   # [F, H, W]    float32 (likewise)
@@ -74,7 +77,9 @@ def run_windows(call_window: Callable[[int], "object"], starts: Sequence[int], g
         local.append((idx, s, _as_tensor(out.rgb), _as_tensor(out.disparity), _as_tensor(out.raymap)))
 
     def result(s, rgb, disp, ray, dev_views):
-        if keep_on_device and dev_views:
+        # tensors are kept only when they really live on a GPU: under gloo / with CPU inputs the fields are numpy like the
+        # reference's, so host-only consumers (the numpy blend) never meet a torch tensor
+        if keep_on_device and dev_views and rgb.is_cuda and disp.is_cuda:
             return WindowResult(s, rgb, disp, ray.cpu().numpy().copy())
         return WindowResult(s, rgb.cpu().numpy(), disp.cpu().numpy(), ray.cpu().numpy())
 
@@ -208,7 +213,11 @@ def _merge_on_device(results: Sequence[WindowResult], *, height: int, width: int
     order as the host path (float32 operands of the scale fit, float64 everything else).  On an MI355X the three passes are HIP
     kernels of libaether_hip.so (csrc/merge_kernels.hip: masked scale-fit reduction, fused scale + cross-fade of disparity and
     colour, back-projection) reading the gathered fp32 window outputs where `run_windows` left them; on any other device the same
-    arithmetic runs as torch operations (CPU tests).  A 192-frame clip (8 windows) costs the host about 21 s of float64 numpy.
+    arithmetic runs as torch operations (CPU tests).  One deliberate difference: the HIP scale fit accumulates Σ m·p·t and Σ m·p² in
+    float64 and divides in float64 before rounding the scale to float32, where the reference (compute_scale, U:847-864) sums and
+    divides in float32 — the kernel's value is the more accurate one and differs from the float32 result by ~1e-7 relative (the
+    tests' tolerance against the reference's own outputs, tests/golden/blend.npz, is 1e-5).
+    A 192-frame clip (8 windows) costs the host about 21 s of float64 numpy.
     One D2H copy of the merged arrays at the end."""
     from . import geometry as G
 
@@ -253,7 +262,9 @@ def _merge_on_device(results: Sequence[WindowResult], *, height: int, width: int
         ov = results[k - 1].start + n_win - t0
         assert end == t0 + ov
         fade_h = np.linspace(1, 0, ov)
-        if native:
+        # the HIP merge kernels take 1..64 overlapping frames; windows that do not overlap (the reference's compute_scale then returns
+        # 0, U:847-864) or overlap by more run the same arithmetic as torch operations on the device
+        if native and 0 < ov <= 64:
             r_disp, r_rgb = up32(r.disparity), up32(r.rgb)
             # scale fit (U:847-864) -> device scalar, then ONE pass: scale, cross-fade of disparity and colour, tail frames
             _lib.check(lib.aether_merge_scale_fit(r_disp.data_ptr(), disp[t0].data_ptr(), ov * H * W, scratch.data_ptr(), 4096,

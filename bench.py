@@ -5,7 +5,7 @@
 
 One "step" = exactly what the reference's loop body does per iteration (P:827-916): concat noisy latents with the
 condition latents, one transformer forward, fp32 cast, one CogVideoXDPMScheduler.step (two generator draws), cast
-back to bf16.  Inputs (synthetic, seeded) and the random-init weights are resident in HBM before the timed region.
+back to bf16 — the element-wise tail as the drop-in pipeline runs it (one HIP kernel, bit-identical to the PyTorch ops).  Inputs (synthetic, seeded) and the random-init weights are resident in HBM before the timed region.
 N > 1: one process per GPU, each rank denoises its own independent window (the reference's sliding windows are
 independent pipeline calls, scripts/demo.py:613-631) -> weak scaling, no data-path collective.
 
@@ -94,7 +94,7 @@ def cpu_baseline(cfg_overrides, S_video_shape, seconds_budget=30.0):
         blk(h, e, temb, rope)
         dt = time.perf_counter() - t0
     steps_per_s = 1.0 / (dt * cfg.num_layers)
-    return {"value": steps_per_s, "unit": "denoise-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": steps_per_s, "unit": "denoise-steps/s", "cores": torch.get_num_threads(), "kind": "port", "method": "sampled-extrapolated",
             "sample": f"1 of {cfg.num_layers} DiT blocks at full size (B=1, S={n_vid + cfg.max_text_seq_length}, fp32 torch-CPU "
                       f"oracle, {dt:.1f} s), extrapolated x{cfg.num_layers}; host has {os.cpu_count()} logical cores"}
 
@@ -115,7 +115,7 @@ def cpu_baseline_vae():
         t0 = time.perf_counter()
         vae.decoder(z)
         td = time.perf_counter() - t0
-    return {"encode_s_per_clip": te * 9 * 41 / 8, "decode_s_per_clip": td * 9 * 11 / 2, "cores": torch.get_num_threads(), "kind": "port",
+    return {"encode_s_per_clip": te * 9 * 41 / 8, "decode_s_per_clip": td * 9 * 11 / 2, "cores": torch.get_num_threads(), "kind": "port", "method": "sampled-extrapolated",
             "sample": f"fp32 torch-CPU oracle: one 8x240x360 encoder tile-chunk ({te:.1f} s) x 46.1, one 2x30x45 decoder tile-chunk ({td:.1f} s) x 49.5"}
 
 
@@ -271,6 +271,21 @@ def windows_mode(args, dev, rank, world, dist):
     dist.destroy_process_group()
 
 
+def windows_leg(args):
+    """BASELINE configs[4] on this GPU (`bench.py --windows`: 192 frames = 8 windows, gather in a one-rank nccl group, device merge) as a child
+    process — RCCL prints a version banner on stdout when its group comes up, and this process's stdout must stay ONE JSON line."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--windows", "--window-steps", str(args.window_steps), "--layers", str(args.layers)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    for ln in reversed(r.stdout.splitlines()):
+        if ln.startswith("{"):
+            d = json.loads(ln)
+            return {"seconds_per_192_frame_clip": d["value"], **d["seconds"], "windows": len(d["config"]["window_starts"]),
+                    "sampler_steps_per_window": d["config"]["sampler_steps_per_window"], "n_gpus": d["n_gpus"], "gather": d["config"]["gather"],
+                    "workload": d["config"]["workload"]}
+    return {"error": (r.stderr or r.stdout)[-400:]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -337,9 +352,10 @@ def main():
     timesteps = sched.timesteps
     ts_host = timesteps.tolist()
 
-    state = {"latents": latents, "old_x0": None, "i": 0}
+    state = {"latents": latents, "old_x0": None, "i": 0, "B": B}
 
     def step():
+        B = state["B"]
         i = state["i"] % len(ts_host)
         if i == 0:
             state["old_x0"] = None
@@ -349,13 +365,11 @@ def main():
         cnd = torch.cat([cond] * 2) if B == 2 else cond
         model_in = torch.cat([model_in, cnd], dim=2)                                          # P:857-859
         noise_pred = model(hidden_states=model_in, encoder_hidden_states=prompt.repeat(B, 1, 1), timestep=t.expand(B),
-                           ofs=None, image_rotary_emb=rope, attention_kwargs=None, return_dict=False)[0].float()
-        if B == 2:
-            u, tx = noise_pred.chunk(2)
-            noise_pred = u + 3.0 * (tx - u)
-        lat, state["old_x0"] = sched.step(noise_pred, state["old_x0"], ts_host[i], ts_host[i - 1] if i > 0 else None, lat,
-                                          generator=gen, return_dict=False)
-        state["latents"] = lat.to(torch.bfloat16)
+                           ofs=None, image_rotary_emb=rope, attention_kwargs=None, return_dict=False)[0]
+        # the element-wise tail exactly as the drop-in pipeline runs it (P:877-916): ONE kernel, bit-identical to the PyTorch sequence
+        lat, state["old_x0"] = sched.step_fused(noise_pred, state["old_x0"], ts_host[i], ts_host[i - 1] if i > 0 else None, lat,
+                                                guidance_scale=3.0 if B == 2 else None, generator=gen)
+        state["latents"] = lat
         state["i"] += 1
 
     def barrier():
@@ -411,31 +425,38 @@ def main():
             "gpu_kernel_ms_per_step_total": total_ms / args.steps,
         }
         if world == 1 and not args.no_extra_legs:
-            # The attention soft-max is exact on every path; what depends on the data is which loop a workgroup may run
-            # (include/aether_hip.h): "default" = tile-pair pipeline for workgroups bounded outright (||q||·max||k|| <= 100), guarded
-            # one-tile paths otherwise.  More measured legs bracket that: refresh on EVERY tile (AETHER_ATTN_EXACT_MAX: the
-            # data-independent floor), the one-tile interleaved and generic loops (A/B), and q/k-norm weights x3 (||q||·||k|| x9
-            # ≈ 104 in the log2 domain: NOT bounded outright, the per-tile guard still passes after each row's first tile).
+            # The attention soft-max is exact on every path (include/aether_hip.h); what differs is the loop.  Legs, each `--steps` timed
+            # steps: the default (tile-pair pipeline, optimistic shift-0 sweep, Q fragments in registers), the same without the Q
+            # registers (round 2's loop), the 64-rows-per-wave kernel with 256- and 512-row workgroups, the CONSERVATIVE path (true-maximum
+            # shift from the first tile, a-posteriori check per tile: no dependence on the data or the weights = the floor), and the worst
+            # case of the default path: q/k-norm weights x10 (log2-domain scores of several hundred: every workgroup's optimistic sweep is
+            # thrown away and redone on the conservative path).
             from aether_amd import _lib as L_
+            att = lambda pr: round(flops_per_launch("attention", B, S, D, FF) * pr["attention"][1] / (pr["attention"][0] * 1e-3) / 1e12, 1)  # noqa: E731
             paths = {"default": {"steps_per_s": steps_per_s, "attention_tflops": line["kernel_tflops"].get("attention")}}
             fl0 = model._flags
-            model.set_flags(fl0 | L_.AETHER_ATTN_EXACT_MAX)
-            dt, pr = timed(1, args.steps)
-            paths["refresh_every_tile"] = {"steps_per_s": args.steps / dt,
-                                           "attention_tflops": round(flops_per_launch("attention", B, S, D, FF) * pr["attention"][1] / (pr["attention"][0] * 1e-3) / 1e12, 1)}
-            for name, fl in (("one_tile_interleave", (fl0 & ~L_.AETHER_ATTN_PAIR_PIPELINE) | L_.AETHER_ATTN_INTERLEAVE),
-                             ("generic_tile", fl0 & ~(L_.AETHER_ATTN_PAIR_PIPELINE | L_.AETHER_ATTN_INTERLEAVE))):      # A/B of the steady-state loops
+            base = fl0 & ~(L_.AETHER_ATTN_ROWS64 | L_.AETHER_ATTN_WG512 | L_.AETHER_ATTN_PAIR_PIPELINE | L_.AETHER_ATTN_QREG | L_.AETHER_ATTN_INTERLEAVE)
+            for name, fl in (("tile_pair_q_from_lds_round2", base | L_.AETHER_ATTN_PAIR_PIPELINE),
+                             ("rows64_256_row_workgroups", base | L_.AETHER_ATTN_ROWS64),
+                             ("rows64_512_row_workgroups", base | L_.AETHER_ATTN_ROWS64 | L_.AETHER_ATTN_WG512),
+                             ("conservative_path_data_independent", fl0 | L_.AETHER_ATTN_EXACT_MAX)):
                 model.set_flags(fl)
                 dt, pr = timed(1, args.steps)
-                paths[name] = {"steps_per_s": args.steps / dt,
-                               "attention_tflops": round(flops_per_launch("attention", B, S, D, FF) * pr["attention"][1] / (pr["attention"][0] * 1e-3) / 1e12, 1)}
+                paths[name] = {"steps_per_s": args.steps / dt, "attention_tflops": att(pr)}
             model.set_flags(fl0)
-            model._weights["qn_w"].mul_(3.0); model._weights["kn_w"].mul_(3.0)
+            model._weights["qn_w"].mul_(10.0); model._weights["kn_w"].mul_(10.0)
             dt, pr = timed(1, args.steps)
-            paths["qk_norm_gain_x3"] = {"steps_per_s": args.steps / dt,
-                                        "attention_tflops": round(flops_per_launch("attention", B, S, D, FF) * pr["attention"][1] / (pr["attention"][0] * 1e-3) / 1e12, 1)}
-            model._weights["qn_w"].div_(3.0); model._weights["kn_w"].div_(3.0)
+            paths["worst_case_every_workgroup_redoes_qk_norm_x10"] = {"steps_per_s": args.steps / dt, "attention_tflops": att(pr)}
+            model._weights["qn_w"].div_(10.0); model._weights["kn_w"].div_(10.0)
             line["attention_paths"] = paths
+            # BASELINE configs[2] / [3] (prediction / planning): classifier-free guidance = B = 2 through the transformer + the combine
+            state.update(B=2, i=0, old_x0=None)
+            dt, pr = timed(1, args.steps)
+            state.update(B=B, i=0, old_x0=None)
+            line["cfg_step"] = {"steps_per_s": args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "batch_through_dit": 2,
+                                "mfma_frac_whole_step": args.steps / dt * 2 * 260.8e12 / (MFMA_PEAK_TFLOPS * 1e12),
+                                "workload": "configs[2]/[3]: guided step (cat, B=2 forward, CFG combine, DPM step)",
+                                "attention_tflops": round(flops_per_launch("attention", 2, S, D, FF) * pr["attention"][1] / (pr["attention"][0] * 1e-3) / 1e12, 1)}
         if world == 1 and not args.no_extra_legs:
             cap = mfma_power_cap_leg()
             if cap is not None:
@@ -444,6 +465,8 @@ def main():
             line["mfma_power_cap"] = cap
         if world == 1 and not args.no_clip:
             line["clip"] = clip_wall_clock(model, dev, args.clip_steps)
+        if world == 1 and not args.no_clip and not args.no_extra_legs:
+            line["windows"] = windows_leg(args)
         if world == 1 and not args.no_extra_legs:
             del model
             torch.cuda.empty_cache()

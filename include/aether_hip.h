@@ -53,6 +53,9 @@ int aether_check_device(void);
 #define AETHER_GEMM_4WAVE 1024      /* flags bit 10: four-wave main loop (one wave per SIMD, 128x128 register tile each, LDS reads and
                                       LDS-DMA issued between the wave's own MFMAs, one barrier per K tile); full rounds only, the
                                       split-K tail launch keeps the eight-wave kernel                                          */
+#define AETHER_GEMM_PERSISTENT 32768 /* flags bit 15 (with bit 2): persistent grid — ceil(tiles / rounds) <= 256 workgroups (236 for the DiT shapes) that
+                                        each own whole tiles; the K tiles of consecutive output tiles form one stream through the LDS buffers (the
+                                        next tile's first operands are requested under the current tile's last k-steps); no tail launch        */
 
 /* C[M,N] = epi(A[M,K] · W[N,K]ᵀ), bf16 in / bf16 out / fp32 accumulate on MFMA.
  * Replaces nn.Linear in CogVideoXBlock / CogVideoXPatchEmbed / proj_out under P:865-875
@@ -111,26 +114,52 @@ int aether_qk_norm_rope(const void* qkv, int B, int S, int H, int n_text, const 
 
 #define AETHER_ATTN_PIPELINED 16  /* flags bit 4: software-pipelined kernel (one workgroup per CU; inside each wave the soft-max
                                      of tile j is interleaved with the MFMAs of P·V(j-1) and K(j+1)·Qᵀ)                    */
-#define AETHER_ATTN_EXACT_MAX 32  /* flags bit 5: ignore kmax2: the shift is refreshed (tile maximum, rescale) on EVERY tile   */
-#define AETHER_ATTN_INTERLEAVE 256 /* flags bit 8: steady-state tiles interleave the soft-max VALU with the wave's own MFMAs     */
-#define AETHER_ATTN_PAIR_PIPELINE 512 /* flags bit 9: workgroups whose rows are all bounded outright (||q||·max||k|| <= 100 over the head)
-                                        run two tiles per iteration with each half's soft-max spread over its neighbours' MFMAs */
+#define AETHER_ATTN_EXACT_MAX 32  /* flags bit 5: conservative path only: no shift-0 sweep, no bound table — every row's shift is a true
+                                     score maximum from its first tile on (generic tiles with the a-posteriori check)               */
+#define AETHER_ATTN_INTERLEAVE 256 /* flags bit 8: tiles that pass the a-priori guard (needs kmax2) interleave the soft-max VALU with
+                                      the wave's own MFMAs, one tile per iteration                                                  */
+#define AETHER_ATTN_PAIR_PIPELINE 512 /* flags bit 9 (default): two tiles per iteration with each half's soft-max spread over its
+                                        neighbours' MFMAs, run OPTIMISTICALLY with shift 0; a workgroup whose finished rows show that
+                                        some exp2 left fp32's range starts over on the conservative path                          */
 #define AETHER_ATTN_TAIL_SPLIT 64 /* flags bit 6: workgroups beyond the last full round of 512 run as 128-row workgroups (2nd launch) */
+#define AETHER_ATTN_DOT2_SUM 2048 /* flags bit 11: row sums from the ROUNDED bf16 P pairs by v_dot2c_f32_bf16 against (1,1): one VALU
+                                     issue per two scores instead of two adds; numerator and denominator then round alike           */
+#define AETHER_ATTN_QREG 4096     /* flags bit 12 (with bit 9): the tile-pair loop keeps the Q fragments in registers (no shift vector to hold
+                                     there) instead of re-reading them from LDS                                                       */
+#define AETHER_ATTN_ROWS64 8192   /* flags bit 13: 64 query rows per wave (4 waves per 256-row workgroup, 2 waves per SIMD): every K / V fragment
+                                     read feeds two MFMAs, Q in registers; optimistic shift-0 sweep + classic online soft-max on redo       */
+#define AETHER_ATTN_WG512 16384   /* flags bit 14 (with bit 13): 8 such waves = 512 query rows per workgroup, one workgroup per CU: half the LDS-DMA
+                                     instructions per MFMA                                                                                */
 
 /* Non-causal flash attention, head_dim 64: O[b,s,h*64+d] = softmax_2(Qh·Khᵀ)·V where softmax_2 uses base 2, i.e.
  * Qh must carry softmax_scale·log2(e) (see aether_qk_norm_rope).  Replaces F.scaled_dot_product_attention in
  * CogVideoXAttnProcessor2_0.  Qh,Kh [B,H,S,64], Vt [B,H,64,Spad], O bf16 [B,S,H*64].
- * kmax2 (fp32 [B*H, Spad/64] or NULL): upper bound of ||k||^2 per (batch, head, 64-key tile).
- * Soft-max (default, lock-step kernel) = exact, with a guarded static shift: each row keeps a shift m that is a true score
- * maximum of the tiles it was last refreshed on (first tile always); a tile whose bound proves s - m <= 100 for all its keys
- * (||q||^2·kmax2[tile] <= (m + 100)^2, m + 100 > 0) is exponentiated against m directly — no tile maximum, no subtraction (m
- * rides in the C operand of the QK^T MFMA), no rescale; any other tile, and every tile when kmax2 is NULL or
- * AETHER_ATTN_EXACT_MAX is set, takes the online step (tile maximum, shift update, rescale).  The choice is per wave and
- * tile and changes only speed: soft-max is shift invariant, results are those of an exact fp32 soft-max either way.
+ * kmax2 (fp32 [B*H, Spad/64] or NULL): upper bound of ||k||^2 per (batch, head, 64-key tile); read only by AETHER_ATTN_INTERLEAVE
+ * and AETHER_ATTN_PIPELINED — the default path needs no bound.
+ * Soft-max = exact on every path (soft-max is invariant under any per-row shift; the running maximum of the online algorithm only
+ * keeps exp2 in range).  Conservative path: each row keeps a shift m that is a true score maximum (of its first tile, then of any
+ * tile that forced a refresh); a tile is exponentiated against m directly — no tile maximum, no subtraction (m rides in the C
+ * operand of the QK^T MFMA), no rescale — and checked afterwards: a partial tile sum above 2^100 (or NaN) makes the wave take the
+ * classic online step on the scores it still holds (tile maximum, shift update, rescale) and exponentiate again.  Default path:
+ * the same with shift 0 for the whole sweep in a two-tile software pipeline; finished rows whose sum is not in [2^-100, inf) or
+ * whose accumulators are not finite make the WORKGROUP redo its sweep on the conservative path.  Either way the results are those
+ * of an exact fp32 soft-max; only speed depends on the data (|log2-domain score| > 100 is needed to leave the fast path).
  * (The software-pipelined variant keeps the round-1 rule: no-maximum path iff ||q||·max||k|| <= 96 for the whole head.)
  * flags: AETHER_GEMM_WIDE_STORE (16-byte epilogue stores), AETHER_ATTN_*. */
 int aether_flash_attn_fwd(const void* Qh, const void* Kh, const void* Vt, void* O, int B, int H, int S, int Spad,
                           const float* kmax2, int flags, void* stream);
+
+/* Element-wise tail of one denoise step in ONE pass (aetherv1_pipeline_cogvideox.py:876-916): fp32 cast of the noise prediction (P:877),
+ * classifier-free-guidance combine uncond + g·(cond − uncond) when nb = 2 (P:895-899), CogVideoXDPMScheduler.step for v-prediction
+ * (P:907-915; x0 = sqrt(a_t)·sample − sqrt(1−a_t)·model_output, prev = m1·sample − m2·d + m_noise·noise with d = x0 on a first-order
+ * step (old_x0 NULL) and m3·x0 − m4·old_x0 otherwise) and the cast back to bf16 (P:916).  model_out bf16 [nb][n], sample / noise bf16 [n]
+ * (the noise is the draw the RETURNED sample uses; the caller makes the reference's draws with its generator, in the reference's
+ * order), scalars = the float64 host values of the schedule cast to fp32.  Writes x0_out fp32 [n] (`pred_original_sample`) and the new
+ * sample as fp32 (prev_f32) and / or bf16 (prev_bf16).  Bit-identical to the eager PyTorch sequence (every intermediate rounded where
+ * PyTorch rounds it, no FMA contraction). */
+int aether_dpm_step(const void* model_out, int nb, float guidance, const void* sample, const float* old_x0, const void* noise,
+                    float a_sqrt, float b_sqrt, float m1, float m2, float m_noise, float m3, float m4, float* x0_out, float* prev_f32,
+                    void* prev_bf16, long n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * 3D-causal VAE kernels (diffusers AutoencoderKLCogVideoX: encode at P:557-618, decode_latents at P:931,936).

@@ -16,10 +16,12 @@ from einops import rearrange
 @torch.no_grad()
 def sample(task, transformer, vae, scheduler, prompt_embeds, *, image=None, goal=None, video=None, raymap=None, height, width,
            num_frames, num_inference_steps=None, guidance_scale=None, use_dynamic_cfg=False, generator=None, fps=12,
-           rope=None, dtype=torch.bfloat16, device="cpu", compute_dtype=None):
+           rope=None, dtype=torch.bfloat16, device="cpu", compute_dtype=None, trace=None):
     """image/goal: [1,3,H,W] in [-1,1]; video: [F,3,H,W]; raymap: [1,F,6,h,w]. Returns (rgb, disparity, raymap) tensors.
     compute_dtype (calibration only): run the three modules in this dtype (e.g. fp32 weights) while every random draw
-    and every inter-module tensor keeps the reference dtype `dtype`, so runs at different precision see the SAME noise."""
+    and every inter-module tensor keeps the reference dtype `dtype`, so runs at different precision see the SAME noise.
+    trace (fixture generation only): a dict that receives the intermediates a full-size fixture records — the video posterior,
+    `condition_latents`, every step's noise prediction, the final latents and the raw decoder outputs."""
     cd = compute_dtype or dtype
     defaults_steps = {"reconstruction": 4, "prediction": 50, "planning": 50}                        # P:257-261
     defaults_g = {"reconstruction": 1.0, "prediction": 3.0, "planning": 3.0}                        # P:262-266
@@ -36,6 +38,8 @@ def sample(task, transformer, vae, scheduler, prompt_embeds, *, image=None, goal
 
     def enc(x):                                                                                       # P:557-576
         dist = vae.encode(x.to(cd)).latent_dist
+        if trace is not None:
+            trace.setdefault("posterior", []).append((dist.mean.float().clone(), dist.logvar.float().clone()))
         if cd == dtype:
             z = dist.sample(generator)
         else:   # same bf16 noise as the reference-dtype run, higher-precision mean/std
@@ -65,6 +69,9 @@ def sample(task, transformer, vae, scheduler, prompt_embeds, *, image=None, goal
         cam = torch.zeros(1, lat_frames, 24, height // 8, width // 8, dtype=dtype)                    # P:672-680
     cond = torch.cat([cond, cam], dim=2)                                                              # P:682
     latents = torch.randn(shape, generator=generator, dtype=dtype) * scheduler.init_noise_sigma       # P:683-686
+    if trace is not None:
+        trace["condition_latents"], trace["initial_latents"], trace["noise_pred"] = cond.clone(), latents.clone(), []
+        on_step = trace.get("on_step")
 
     old_x0 = None
     g_now = guidance_scale
@@ -84,6 +91,8 @@ def sample(task, transformer, vae, scheduler, prompt_embeds, *, image=None, goal
         lat_in = torch.cat([lat_in, c_in], dim=2)                                                     # P:857-859
         pred = transformer(hidden_states=lat_in.to(cd), encoder_hidden_states=prompt_embeds.repeat(lat_in.shape[0], 1, 1).to(cd),
                            timestep=t.expand(lat_in.shape[0]), ofs=None, image_rotary_emb=rope, return_dict=False)[0].float()
+        if trace is not None:
+            trace["noise_pred"].append(pred.clone())
         if use_dynamic_cfg:                                                                           # P:879-893
             g_now = 1 + guidance_scale * ((1 - math.cos(math.pi * ((num_inference_steps - t.item()) / num_inference_steps) ** 5.0)) / 2)
         if do_cfg:                                                                                    # P:895-899
@@ -92,9 +101,16 @@ def sample(task, transformer, vae, scheduler, prompt_embeds, *, image=None, goal
         latents, old_x0 = scheduler.step(pred, old_x0, t, timesteps[i - 1] if i > 0 else None, latents,
                                          generator=generator, return_dict=False)                      # P:907-915
         latents = latents.to(dtype)                                                                   # P:916
+        if trace is not None and on_step is not None:
+            on_step(i, latents)
+    if trace is not None:
+        trace["final_latents"] = latents.clone()
 
     def dec(z):                                                                                       # decode_latents
-        return vae.decode((1 / sf * z.permute(0, 2, 1, 3, 4)).to(cd)).sample.to(dtype)
+        out = vae.decode((1 / sf * z.permute(0, 2, 1, 3, 4)).to(cd)).sample
+        if trace is not None:
+            trace.setdefault("decoded", []).append(out.float().clone())
+        return out.to(dtype)
 
     rgb = dec(latents[:, :, :16])                                                                     # P:925-934
     rgb = (rgb[0].permute(1, 0, 2, 3) / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).float()

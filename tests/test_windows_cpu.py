@@ -70,10 +70,10 @@ _WORKER = textwrap.dedent('''
         np.savez(%(out)r, rgb=blend_rgb(res, len(video)), disparity=np.stack([r.disparity for r in res]), raymap=np.stack([r.raymap for r in res]),
                  starts=np.asarray([r.start for r in res]))
     if world > 1:
-        kept = run_windows(call, starts, keep_on_device=True)       # gathered rgb / disparity stay tensors, raymaps numpy
+        kept = run_windows(call, starts, keep_on_device=True)       # tensors are kept only on a CUDA gather device: under gloo everything is numpy
         if res is not None:
-            assert all(isinstance(k.rgb, torch.Tensor) and isinstance(k.disparity, torch.Tensor) and isinstance(k.raymap, np.ndarray) for k in kept)
-            assert all(np.array_equal(k.rgb.numpy(), r.rgb) and np.array_equal(k.disparity.numpy(), r.disparity)
+            assert all(isinstance(k.rgb, np.ndarray) and isinstance(k.disparity, np.ndarray) and isinstance(k.raymap, np.ndarray) for k in kept)
+            assert all(np.array_equal(k.rgb, r.rgb) and np.array_equal(k.disparity, r.disparity)
                        and np.array_equal(k.raymap, r.raymap) and k.start == r.start for k, r in zip(kept, res))
         dist.barrier(); dist.destroy_process_group()
 ''')

@@ -1,0 +1,114 @@
+"""Generates the FULL-DEPTH, FULL-GEOMETRY parity fixtures (tests/golden/fullsize_{dit,clip}.npz) with the fp32 CPU oracle.
+
+Run offline in the build container (no GPU needed; ~1 h on 8 vCPUs, 30 GB of RAM):
+
+    python tools/make_fullsize_golden.py            # both stages
+    python tools/make_fullsize_golden.py dit        # one stage
+
+  dit   ONE transformer forward, all 42 blocks, S = 15 076 tokens, B = 1 (P:865-875) on seeded inputs
+        -> the noise prediction [1, 11, 56, 60, 90] as float16 (6.7 MB).
+  clip  the whole reconstruction call (P:690-965) at 41 x 480 x 720 with the reference's default 4 steps and a CPU generator
+        (seed 42): tiled 41-frame VAE encode (all 9 tiles, all 5 frame chunks) -> posterior sample -> 4 x (42-block forward +
+        SDE-DPM++ step) -> two tiled 11 -> 41-frame decodes.  Recorded: the posterior (mean float16, log-variance sub-sampled),
+        the final latents (exact bf16 bits), per-step latents (sub-sampled), per-step noise-prediction norms, the decoded rgb
+        clip and the disparity (every 8th row / column of every frame).  12 MB.
+
+The three modules are the oracle restatements (oracle/dit.py, oracle/vae.py, PARITY UNPINNED against diffusers itself) in fp32
+with bf16-representable weights; every random draw and every tensor passed between modules keeps the reference dtype (bf16),
+`compute_dtype=float32` of oracle.pipeline.sample.  tests/test_fullsize_parity_gpu.py rebuilds the same weights / inputs from
+the seeds in tools/fullsize_cases.py on the GPU box and compares the HIP path with these files.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import fullsize_cases as fc  # noqa: E402
+
+
+def log(msg):
+    print(f"[{time.strftime('%H:%M:%S')}] {msg}", flush=True)
+
+
+def stage_dit(dit):
+    hidden, text, t = fc.dit_inputs()
+    rope = fc.rope_tables()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        out = dit(hidden.float(), text.float(), t, image_rotary_emb=rope)[0]
+    dt = time.perf_counter() - t0
+    log(f"dit: 42-block forward at S=15076 took {dt:.1f} s; |out| max {out.abs().max():.3f} rms {out.pow(2).mean().sqrt():.4f}")
+    assert torch.isfinite(out).all()
+    meta = dict(seconds_cpu=dt, threads=torch.get_num_threads(), torch=torch.__version__, dit_seed=fc.DIT_SEED,
+                input_seed=fc.DIT_INPUT_SEED, timestep=int(t[0]), out_max=float(out.abs().max()), out_rms=float(out.pow(2).mean().sqrt()),
+                input_sum=float(hidden.float().sum()), layers=len(dit.transformer_blocks))
+    np.savez(os.path.join(fc.GOLDEN_DIR, "fullsize_dit.npz"), out=out.numpy().astype(np.float16), meta=json.dumps(meta))
+    log("dit: wrote tests/golden/fullsize_dit.npz")
+
+
+def stage_clip(dit):
+    from aether_amd.scheduler import CogVideoXDPMScheduler
+    from oracle.pipeline import sample
+    vae = fc.build_oracle_vae()
+    video = fc.clip_video()
+    v = fc.video_as_model_input(video)
+    times = {}
+    mark = [time.perf_counter()]
+    step_lat = []
+
+    def on_step(i, latents):
+        now = time.perf_counter()
+        times[f"step{i}"] = now - mark[0]
+        mark[0] = now
+        step_lat.append(latents[:, :, :, ::3, ::3].clone())
+        log(f"clip: step {i} done ({times[f'step{i}']:.1f} s)")
+
+    trace = {"on_step": on_step}
+    t0 = time.perf_counter()
+    rgb, disp, rm = sample("reconstruction", dit, vae, CogVideoXDPMScheduler(), fc.prompt_embeds(), video=v, height=fc.HEIGHT,
+                           width=fc.WIDTH, num_frames=fc.FRAMES, num_inference_steps=fc.CLIP_STEPS,
+                           generator=torch.Generator().manual_seed(fc.CLIP_SEED), rope=fc.rope_tables(),
+                           compute_dtype=torch.float32, trace=trace)
+    total = time.perf_counter() - t0
+    log(f"clip: whole reconstruction call took {total:.1f} s")
+    mean, logvar = trace["posterior"][0]
+    s = fc.DEC_STRIDE
+    meta = dict(seconds_cpu_total=total, step_seconds=times, threads=torch.get_num_threads(), torch=torch.__version__,
+                dit_seed=fc.DIT_SEED, vae_seed=fc.VAE_SEED, clip_seed=fc.CLIP_SEED, steps=fc.CLIP_STEPS,
+                noise_pred_rms=[float(p.pow(2).mean().sqrt()) for p in trace["noise_pred"]],
+                noise_pred_max=[float(p.abs().max()) for p in trace["noise_pred"]],
+                video_sum=float(video.astype(np.float64).sum()))
+    meta["fixture_layout"] = f"decoded / post-processed arrays keep every {s}th row and column of every frame (DEC_STRIDE); per-step latents every 6th"
+    np.savez(os.path.join(fc.GOLDEN_DIR, "fullsize_clip.npz"),
+             posterior_mean=mean.numpy().astype(np.float16),                              # [1,16,11,60,90]
+             posterior_logvar_s2=logvar[..., ::2, ::2].numpy().astype(np.float16),
+             final_latents_bits=fc.bf16_bits(trace["final_latents"]),                     # [1,11,56,60,90], exact (the raymap output is a re-arrangement of it)
+             step_latents_s6=np.stack([fc.bf16_bits(x[..., ::2, ::2]) for x in step_lat]),
+             rgb_decoded_s8=trace["decoded"][0][:, :, :, ::s, ::s].numpy().astype(np.float16),    # raw decoder output [1,3,41,60,90]
+             rgb_s8=rgb[:, ::s, ::s].numpy().astype(np.float16),                           # post-processed outputs (P:925-949)
+             disparity_s8=disp[:, ::s, ::s].numpy().astype(np.float16),
+             meta=json.dumps(meta))
+    log("clip: wrote tests/golden/fullsize_clip.npz")
+
+
+def main():
+    stages = sys.argv[1:] or ["dit", "clip"]
+    torch.set_num_threads(os.cpu_count() or 8)
+    log(f"building the 42-block oracle transformer (seed {fc.DIT_SEED}) ...")
+    t0 = time.perf_counter()
+    dit, _ = fc.build_oracle_dit()
+    log(f"... {time.perf_counter() - t0:.1f} s")
+    if "dit" in stages:
+        stage_dit(dit)
+    if "clip" in stages:
+        stage_clip(dit)
+
+
+if __name__ == "__main__":
+    main()

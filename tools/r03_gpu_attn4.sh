@@ -1,0 +1,7 @@
+#!/bin/bash
+OUT=gpurun_out/r03b1
+mkdir -p $OUT
+python -m pytest tests/test_kernels_gpu.py -x -q -k "flash" 2>&1 | tail -3
+for fl in 4609 8193 24577 4609 8193 24577; do
+  python tools/gpu_attn_probe.py --flags $fl --iters 30 | tee -a $OUT/attn_probe4.jsonl
+done

@@ -235,6 +235,9 @@ extern "C" int aether_dit_forward(AetherDit* h, const void* hidden, const void* 
     // softmax scale 1/sqrt(64) and log2(e) folded into Q in fp32 before its single rounding to bf16: scores arrive in
     // the log2 domain.  kmax receives max ||k||^2 per (batch, head, 64-key tile) of the current layer (bounded-score soft-max path).
     const float q_scale = 0.125f * 1.4426950408889634f;
+    // the per-tile bound table is read only by the a-priori-guarded / round-1 attention paths; the default (optimistic) sweeps need none
+    const bool need_kmax = (fl & (AETHER_ATTN_INTERLEAVE | AETHER_ATTN_PIPELINED)) != 0 && !(fl & AETHER_ATTN_EXACT_MAX);
+    if (!need_kmax) kmax = nullptr;
     for (int i = 0; i < L; ++i) {
         const float* m1 = mod + (size_t)i * 12 * D;  // shift, scale, gate, enc_shift, enc_scale, enc_gate
         const float* m2 = m1 + 6 * D;

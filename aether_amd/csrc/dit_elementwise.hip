@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void qkv_prepare_kernel(QkArgs p) {
         for (int e = 0; e < 8; ++e) tile[ch * 8 + e][sl] = ok[i] ? rv[i][e] : (unsigned short)0;
         // ||k||^2 of the rounded bf16 key (what attention reads): the 64 elements of a token sit in the 8 lanes sharing `sl`
         float n2 = 0.f;
-        if (ok[i]) {
+        if (ok[i] && p.kmax2 != nullptr) {
             const unsigned kwd[4] = {k.x, k.y, k.z, k.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -286,8 +286,10 @@ __global__ __launch_bounds__(256) void qkv_prepare_kernel(QkArgs p) {
                 n2 += lo * lo; n2 += hi2 * hi2;
             }
         }
-        n2 += __shfl_xor(n2, 1, 64); n2 += __shfl_xor(n2, 2, 64); n2 += __shfl_xor(n2, 4, 64);
-        kmx = fmaxf(kmx, n2);
+        if (p.kmax2 != nullptr) {
+            n2 += __shfl_xor(n2, 1, 64); n2 += __shfl_xor(n2, 2, 64); n2 += __shfl_xor(n2, 4, 64);
+            kmx = fmaxf(kmx, n2);
+        }
     }
     if (p.kmax2 != nullptr) {
         kmx = wave_max(kmx);

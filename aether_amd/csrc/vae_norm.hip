@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void groupnorm_finalize_kernel(const float* __
 // A thread keeps the 2 x zC weights of its channel in registers and walks the block's voxels; the zC latent values of a voxel
 // are wave-uniform (staged through LDS once per block), the two outputs of consecutive threads are consecutive floats.
 constexpr int SC_ZC = 16;       // latent channels (CogVideoX: 16)
-constexpr int SC_VOX = 64;      // voxels per block
+constexpr int SC_VOX = 16;      // voxels per block (64 left the decoder's 2 700-voxel latents on 43 workgroups per tile: latency-bound, 21 us per call)
 __global__ __launch_bounds__(256) void spatial_cond_kernel(const unsigned short* __restrict__ zq, int zC, int C,
                                                            const float* __restrict__ wy, const float* __restrict__ by,
                                                            const float* __restrict__ wb, const float* __restrict__ bb,

@@ -89,7 +89,7 @@ def test_vae_encode_whole_clip(cuda, native_vae):
     m, ml = fc.metrics(mean, ref_mean), fc.metrics(logvar[..., ::2, ::2], ref_logvar)
     print(f"\n[fullsize] VAE encode {fc.FRAMES}x{fc.HEIGHT}x{fc.WIDTH}, all tiles and chunks, vs fp32 oracle: posterior mean rel-L2 {m['rel_l2']:.3e}  "
           f"latents L-inf {m['linf']:.4f} ({100 * m['linf_rel']:.2f} % of max|ref| {m['ref_max']:.3f}); log-variance L-inf {100 * ml['linf_rel']:.2f} %")
-    assert m["rel_l2"] <= 2.0e-2 and m["linf_rel"] <= 0.04, m
+    assert m["rel_l2"] <= 2.0e-2 and m["linf_rel"] <= 0.04, m        # measured 1.13e-2 / 1.80 %; log-variance 1.35 %
     assert ml["linf_rel"] <= 0.04, ml
 
 
@@ -108,7 +108,7 @@ def test_vae_decode_whole_clip(cuda, native_vae):
     p = fc.psnr((got / 2 + 0.5).clamp(0, 1), (ref / 2 + 0.5).clamp(0, 1))
     print(f"\n[fullsize] VAE decode {fc.LAT_F}x{fc.LAT_H}x{fc.LAT_W} -> {fc.FRAMES}x{fc.HEIGHT}x{fc.WIDTH}, all tiles and chunks (every {s}th row/column compared): "
           f"rel-L2 {m['rel_l2']:.3e}  L-inf {m['linf']:.4f}  pixel PSNR {p:.1f} dB")
-    assert p >= 38.0 and m["rel_l2"] <= 2e-2, (p, m)
+    assert p >= 42.0 and m["rel_l2"] <= 1.5e-2, (p, m)              # measured 49.5 dB / 6.2e-3
 
 
 def test_reconstruction_clip_four_steps(cuda, native_dit, native_vae):
@@ -139,5 +139,6 @@ def test_reconstruction_clip_four_steps(cuda, native_dit, native_vae):
           f"final latents rel-L2 {ml['rel_l2']:.3e}  L-inf {ml['linf']:.4f} ({100 * ml['linf_rel']:.2f} % of max|ref| {ml['ref_max']:.2f}); "
           f"rgb PSNR {p_rgb:.1f} dB; disparity rel-L2 {m_disp['rel_l2']:.3e}; raymap rel-L2 {m_ray['rel_l2']:.3e}")
     assert out.rgb.shape == (fc.FRAMES, fc.HEIGHT, fc.WIDTH, 3) and np.isfinite(out.rgb).all()
-    assert ml["rel_l2"] <= 5.0e-2 and ml["linf_rel"] <= 0.15, ml
-    assert p_rgb >= 30.0 and m_disp["rel_l2"] <= 5e-2 and m_ray["rel_l2"] <= 5e-2, (p_rgb, m_disp, m_ray)
+    # measured: latents 1.03e-2 / 1.53 %, rgb 39.1 dB, disparity 2.2e-2 (a squared quantity: twice the relative error), raymap 9.6e-3
+    assert ml["rel_l2"] <= 2.2e-2 and ml["linf_rel"] <= 0.04, ml
+    assert p_rgb >= 34.0 and m_disp["rel_l2"] <= 4.5e-2 and m_ray["rel_l2"] <= 2.2e-2, (p_rgb, m_disp, m_ray)

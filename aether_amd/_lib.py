@@ -18,6 +18,7 @@ AETHER_GEMM_WIDE_STORE = 1
 AETHER_GEMM_PINGPONG = 4      # ping-pong main loop (see include/aether_hip.h)
 AETHER_GEMM_PINGPONG2 = 8
 AETHER_GEMM_PERSISTENT = 32768  # persistent grid (236 workgroups for the DiT shapes, whole tiles each, no tail launch)
+AETHER_DIT_FUSE_QKV_PREP = 65536  # aether_dit_forward: q/k norm + RoPE + V transpose in the qkv GEMM's epilogue
 AETHER_GEMM_4WAVE = 1024      # four-wave main loop (one wave per SIMD, in-wave interleaving)
 AETHER_ATTN_PIPELINED = 16    # attention: software-pipelined kernel
 AETHER_ATTN_EXACT_MAX = 32    # attention: conservative path only (true-maximum shift from tile 0, a-posteriori check per tile)
@@ -64,6 +65,9 @@ SIGNATURES = {
     "aether_patchify": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "aether_unpatchify": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "aether_qk_norm_rope": (_i, [_vp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _f, _fp, _fp, _f, _vp, _vp, _vp, _i, _fp, _vp]),
+    "aether_qk_norm_rope_tail": (_i, [_vp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _f, _fp, _fp, _f, _vp, _vp, _vp, _i, _i, _vp]),
+    "aether_vt_pad_zero": (_i, [_vp, _i, _i, _i, _vp]),
+    "aether_gemm_qkv_prep": (_i, [_vp, _i, _vp, _i, _fp, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _f, _fp, _fp, _f, _vp, _vp, _vp, _i, _i, _vp]),
     "aether_flash_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _fp, _i, _vp]),
     "aether_dpm_step": (_i, [_vp, _i, _f, _vp, _fp, _vp, _f, _f, _f, _f, _f, _f, _f, _fp, _fp, _vp, C.c_long, _vp]),
     "aether_conv_gemm_bf16": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _fp, _vp, _i, _fp, _sz, _i, _vp]),

@@ -74,14 +74,14 @@ AE_DEV void gemm_tile_coords(int wgid, int tiles_m, int tiles_n, int& tile_m, in
 // ---- fused epilogue of one output tile (shared by the one-tile-per-workgroup kernel below and the persistent kernel) -------------------
 // acc[mt][nt][r] = C[m][n], m = m0 + (wm*MT + mt)*32 + l32,  n = n0 + (wn*NT + nt)*32 + 8*(r>>2) + 4*hi + (r&3)
 template <int WM, int WN, int MT, int NT, int EPI, bool WIDE_STORE>
-AE_DEV void gemm_epilogue(const GemmArgs& p, const f32x16 (&acc)[MT][NT], int m0, int n0, int wm, int wn, int l32, int hi) {
+AE_DEV void gemm_epilogue(const GemmArgs& p, const f32x16 (&acc)[MT][NT], int m0, int n0, int wm, int wn, int l32, int hi, char* lds = nullptr) {
     if constexpr (EPI == EPI_QKV_PREP) {
         // The wave's 64 columns are ONE head of q, k or v (NT * 32 == 64, tiles start on multiples of 256 columns).  What aether_qk_norm_rope
         // does in a pass of its own happens here on the accumulators: the projection is rounded to bf16 exactly as the plain epilogue
         // would store it, then — q, k — LayerNorm over the head's 64 values (32 in this lane, 32 in lane ^ 32), affine, rotary embedding of
         // the video rows (adjacent pairs: both elements of a pair sit in one lane), soft-max scale on q, one rounding, 16-byte stores into
-        // the head-major [B, H, S, 64] layout; — v — a transposed 2-byte store into V^T [B, H, 64, Spad] (32 lanes of a store instruction
-        // write 32 consecutive tokens of one d: 64-byte segments).
+        // the head-major [B, H, S, 64] layout; — v — transposed through the wave's own 16 KiB of the (now idle) operand buffers in LDS and
+        // written to V^T [B, H, 64, Spad] as 16-byte pieces (after the main loop's last barrier no wave reads or DMA-writes LDS any more).
         static_assert(NT * 32 == 64, "one head per wave");
         const int D = p.heads * 64;
         const int ncol0 = n0 + wn * 64;
@@ -109,17 +109,14 @@ AE_DEV void gemm_epilogue(const GemmArgs& p, const f32x16 (&acc)[MT][NT], int m0
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) v[nt][4 * g + c] = bf16_bits_to_f32(f32_to_bf16_bits(acc[mt][nt][4 * g + c] + bv[nt][g][c]));
-            if (part == 2) {                                        // wave-uniform
-                unsigned short* vt = p.Vt + ((size_t)(b * p.heads + head) * 64) * p.Spad + s;
-                if (m_ok) {
+            if (part == 2) {                                        // wave-uniform: this head's values go into the wave's 16 KiB of LDS, [d][token]
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const int d = nt * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
-                            vt[(size_t)d * p.Spad] = f32_to_bf16_bits(v[nt][e]);
-                        }
-                }
+                    for (int e = 0; e < 16; ++e) {
+                        const int d = nt * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
+                        *(unsigned short*)(lds + d * (MT * 64) + (mt * 32 + l32) * 2) = f32_to_bf16_bits(v[nt][e]);
+                    }
                 continue;
             }
             float sum = 0.f;
@@ -172,6 +169,38 @@ AE_DEV void gemm_epilogue(const GemmArgs& p, const f32x16 (&acc)[MT][NT], int m0
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
                         if (m_ok) *(uint2*)(orow + nt * 32 + 8 * g + 4 * hi) = make_uint2(pk[g][0], pk[g][1]);
+                }
+            }
+        }
+        if (part == 2) {
+            // V^T write-out: 16-byte pieces = 8 consecutive tokens of one d (a transposed 2-byte store per value costs 128 store
+            // instructions per lane and tile — store issue, not bandwidth, made V tiles 45 % slower than q / k tiles).  16 lanes cover one d row
+            // of the wave's 128 tokens: 256 contiguous bytes per d in LDS and in V^T.  Pieces that straddle the end of the rows, a batch
+            // boundary, or whose first token is not a multiple of 8 in its batch item (S % 8 != 0, b > 0) fall back to narrower stores.
+            const int lane = 32 * hi + l32;
+            constexpr int PIECES = MT * 32 / 8;                     // 16-byte pieces per d row (16)
+#pragma unroll
+            for (int j = 0; j < 64 * PIECES / 64; ++j) {
+                const int q = j * 64 + lane;
+                const int d = q / PIECES, t8 = q - d * PIECES;
+                const uint4 w = *(const uint4*)(lds + d * (MT * 64) + t8 * 16);
+                const int m = m0 + wm * (MT * 32) + t8 * 8;
+                if (m >= p.M) continue;
+                const int b = m / S, s = m - b * S;
+                unsigned short* dst = p.Vt + ((size_t)(b * p.heads + head) * 64 + d) * p.Spad + s;
+                const bool whole = m + 7 < p.M && s + 7 < S;
+                if (whole && (s & 7) == 0) *(uint4*)dst = w;
+                else if (whole && (s & 3) == 0) { *(uint2*)dst = make_uint2(w.x, w.y); *(uint2*)(dst + 4) = make_uint2(w.z, w.w); }
+                else {
+                    const unsigned wd[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int me = m + e;
+                        if (me < p.M) {
+                            const int be = me / S, se = me - be * S;
+                            p.Vt[((size_t)(be * p.heads + head) * 64 + d) * p.Spad + se] = (unsigned short)(wd[e >> 1] >> (16 * (e & 1)));
+                        }
+                    }
                 }
             }
         }
@@ -645,7 +674,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
         }
         return;
     }
-    gemm_epilogue<WM, WN, MT, NT, EPI, WIDE_STORE>(p, acc, m0, n0, wm, wn, l32, hi);
+    gemm_epilogue<WM, WN, MT, NT, EPI, WIDE_STORE>(p, acc, m0, n0, wm, wn, l32, hi, smem + wave * (MT * 32 * 64 * 2));
 }
 
 }  // namespace aether

@@ -299,6 +299,8 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the attention-path legs and the VAE leg (profiling runs)")
     ap.add_argument("--windows", action="store_true", help="BASELINE configs[4] end to end instead of the step benchmark: 192-frame clip, "
                     "8 windows (stride 24) sharded over the ranks, gather to rank 0 over RCCL, device merge; reports s per clip")
+    ap.add_argument("--dit-flags-or", type=int, default=0, help="A/B: OR these AETHER_* bits into the transformer's default flags")
+    ap.add_argument("--dit-flags-clear", type=int, default=0, help="A/B: clear these AETHER_* bits from the transformer's default flags")
     ap.add_argument("--window-steps", type=int, default=4, help="sampler steps per window in --windows mode (reference default: 4)")
     args = ap.parse_args()
 
@@ -337,6 +339,8 @@ def main():
     B = 2 if args.cfg else 1
     F_, H_, W_ = 11, 60, 90
     model = AetherTransformer3D({"num_layers": args.layers}, device=dev).init_random_weights(seed=0)
+    if args.dit_flags_or or args.dit_flags_clear:
+        model.set_flags((model._flags | args.dit_flags_or) & ~args.dit_flags_clear)
     c = model.config
     D, FF = model.inner_dim, 4 * model.inner_dim
     S = c.max_text_seq_length + F_ * (H_ // 2) * (W_ // 2)

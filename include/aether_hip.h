@@ -112,6 +112,29 @@ int aether_qk_norm_rope(const void* qkv, int B, int S, int H, int n_text, const 
                         const float* kn_w, const float* kn_b, float eps, const float* cos_t, const float* sin_t,
                         float q_scale, void* Qh, void* Kh, void* Vt, int Spad, float* kmax2, void* stream);
 
+/* The same for the tokens s >= first_token (a multiple of 64) only — the tail rows of a forward whose leading rows were prepared in the
+ * epilogue of aether_gemm_qkv_prep.  Covers the ragged last 64-token tile, i.e. also zeroes the pad columns of Vt. */
+int aether_qk_norm_rope_tail(const void* qkv, int B, int S, int H, int n_text, const float* qn_w, const float* qn_b, const float* kn_w,
+                             const float* kn_b, float eps, const float* cos_t, const float* sin_t, float q_scale, void* Qh, void* Kh,
+                             void* Vt, int Spad, int first_token, void* stream);
+
+/* Zero the pad columns [S, Spad) of Vt [rows = B*H*64, Spad] (attention multiplies them by p = 0: they must be finite). */
+int aether_vt_pad_zero(void* Vt, int rows, int S, int Spad, void* stream);
+
+/* Fused qkv projection + attention-operand preparation (north_star: "RMSNorm/RoPE as fused epilogues"): A [M,K] · Wqkv [3·heads·64, K]ᵀ + bias
+ * with the work of aether_qk_norm_rope done on the accumulators in the GEMM epilogue — the projection is rounded to bf16 as the plain
+ * epilogue would store it, then q / k: LayerNorm(64) per head + affine + 3-D RoPE on the video rows + q_scale on q -> Qh / Kh [B,H,S,64];
+ * v: transposed store -> Vt [B,H,64,Spad] (pad columns NOT written: aether_vt_pad_zero / aether_qk_norm_rope_tail).  M = rows of whole
+ * batch items, or the leading rows of one (the caller may keep a partly filled last round of tiles for the un-fused path).  Replaces
+ * to_q / to_k / to_v + norm_q / norm_k + apply_rotary_emb of diffusers' CogVideoXAttnProcessor2_0 (reference call P:865-875).
+ * flags: AETHER_GEMM_WIDE_STORE, AETHER_GEMM_PINGPONG*. */
+int aether_gemm_qkv_prep(const void* A, int lda, const void* W, int ldw, const float* bias, int M, int heads, int K, int S, int n_text,
+                         const float* qn_w, const float* qn_b, const float* kn_w, const float* kn_b, float eps, const float* cos_t,
+                         const float* sin_t, float q_scale, void* Qh, void* Kh, void* Vt, int Spad, int flags, void* stream);
+
+#define AETHER_DIT_FUSE_QKV_PREP 65536 /* flags bit 16 (aether_dit_forward): q/k norm + RoPE + V transpose in the qkv GEMM's epilogue
+                                          (aether_gemm_qkv_prep) instead of a pass of their own                                     */
+
 #define AETHER_ATTN_PIPELINED 16  /* flags bit 4: software-pipelined kernel (one workgroup per CU; inside each wave the soft-max
                                      of tile j is interleaved with the MFMAs of P·V(j-1) and K(j+1)·Qᵀ)                    */
 #define AETHER_ATTN_EXACT_MAX 32  /* flags bit 5: conservative path only: no shift-0 sweep, no bound table — every row's shift is a true

@@ -518,3 +518,37 @@ def test_dpm_step_fused_is_bit_identical(cuda, hip_lib, nb, steps):
     for i, ((la, xa), (lb, xb)) in enumerate(zip(*outs)):
         assert torch.equal(la, lb), f"latents differ at step {i}: {(la.float() - lb.float()).abs().max().item()}"
         assert torch.equal(xa, xb), f"x0 differs at step {i}: {(xa - xb).abs().max().item()}"
+
+
+@pytest.mark.parametrize("B,H,S,n_text,K", [(1, 8, 700, 226, 512), (2, 4, 333, 20, 256), (1, 4, 1000, 0, 128)])
+@pytest.mark.parametrize("flags", [5, 4])
+def test_gemm_qkv_prep_matches_the_two_pass_path(cuda, hip_lib, B, H, S, n_text, K, flags):
+    """aether_gemm_qkv_prep = the qkv projection with q/k LayerNorm(64) + RoPE + scale and the V transpose in its epilogue, against
+    aether_gemm_bf16 followed by aether_qk_norm_rope.  V^T involves no arithmetic beyond the projection's rounding: bit-identical.  q / k
+    sum the 64 values of a head in a different order (32 + 32 across two lanes instead of 8 x 8), so the normalised values may differ in
+    the last bf16 bit of a few elements — and both must match the fp32 reference of the preparation like the stand-alone kernel does."""
+    from aether_amd import ops
+    from aether_amd._lib import ATTN_Q_SCALE
+    g = torch.Generator().manual_seed(S + K)
+    A = torch.randn(B * S, K, generator=g).to(torch.bfloat16)
+    W = (torch.randn(3 * H * 64, K, generator=g) * 1.5 / math.sqrt(K)).to(torch.bfloat16)
+    bias = 0.1 * torch.randn(3 * H * 64, generator=g)
+    _, qn_w, qn_b, kn_w, kn_b, cos, sin = _attn_inputs(B, H, S, n_text, 3)
+    c = lambda t: t.to(cuda)  # noqa: E731
+    qkv = ops.gemm_bf16(c(A), c(W), c(bias), ops.AETHER_EPI_BIAS, flags=flags).view(B, S, 3 * H * 64)
+    Q0, K0, V0 = ops.qk_norm_rope(qkv, H, n_text, c(qn_w), c(qn_b), c(kn_w), c(kn_b), 1e-6, c(cos), c(sin), ATTN_Q_SCALE)
+    Q1, K1, V1 = ops.gemm_qkv_prep(c(A), c(W), c(bias), H, S, n_text, c(qn_w), c(qn_b), c(kn_w), c(kn_b), 1e-6, c(cos), c(sin), ATTN_Q_SCALE, flags=flags)
+    torch.cuda.synchronize()
+    assert torch.equal(V0, V1)
+    for name, a, b in (("q", Q0, Q1), ("k", K0, K1)):
+        a, b = a.float(), b.float()
+        assert torch.isfinite(b).all()
+        differ = (a != b).float().mean().item()
+        worst = ((a - b).abs() / a.abs().clamp_min(1e-3)).max().item()
+        assert differ < 0.02 and worst <= 2.0 ** -6, (name, differ, worst)
+    if B == 1:          # leading rows only (what aether_dit_forward does when the last round of tiles would be mostly empty)
+        rows = 512
+        Q2, K2, V2 = ops.gemm_qkv_prep(c(A), c(W), c(bias), H, S, n_text, c(qn_w), c(qn_b), c(kn_w), c(kn_b), 1e-6, c(cos), c(sin), ATTN_Q_SCALE, flags=flags, rows=rows)
+        torch.cuda.synchronize()
+        assert torch.equal(Q2[:, :, :rows], Q1[:, :, :rows]) and torch.equal(K2[:, :, :rows], K1[:, :, :rows]) and torch.equal(V2[..., :rows], V1[..., :rows])
+        assert float(Q2[:, :, rows:].abs().max()) == 0 and torch.isnan(V2[..., rows:S].float()).all()      # rows beyond are untouched

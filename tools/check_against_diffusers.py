@@ -8,6 +8,11 @@ Every "[UPSTREAM-UNVERIFIED]" item of SURVEY.md Appendix A (RoPE pair layout, Ad
 first-frame rules of the resamplers, DPM noise-draw count ...) is exercised by one of the three checks.
 
     python tools/check_against_diffusers.py        # exit 0 = all restatements match diffusers, 3 = diffusers missing
+    python tools/check_against_diffusers.py --self-test
+        runs the SAME script body against a stand-in `diffusers` module whose three classes are thin adapters around this repo's own
+        restatements (constructor keywords, call signatures and attribute names as the script uses them on the real package): proves
+        nothing about diffusers, but every line of the check executes, so a typo does not surface on the day diffusers is available
+        (tests/test_host_cpu.py runs it).
 """
 import os
 import sys
@@ -18,7 +23,32 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def _install_standin():
+    """A module named `diffusers` exposing the three classes this script imports, backed by the oracle restatements."""
+    import types
+
+    from aether_amd.scheduler import CogVideoXDPMScheduler as OurScheduler
+    from oracle.dit import DitConfig, OracleTransformer3D
+    from oracle.vae import OracleVAE, VaeConfig
+
+    class CogVideoXTransformer3DModel(OracleTransformer3D):
+        def __init__(self, **kw):
+            super().__init__(DitConfig(**kw))
+
+    class AutoencoderKLCogVideoX(OracleVAE):
+        def __init__(self, down_block_types=None, up_block_types=None, **kw):
+            assert len(down_block_types) == len(up_block_types) == len(kw["block_out_channels"])
+            super().__init__(VaeConfig(**kw))
+
+    mod = types.ModuleType("diffusers")
+    mod.CogVideoXTransformer3DModel, mod.AutoencoderKLCogVideoX, mod.CogVideoXDPMScheduler = CogVideoXTransformer3DModel, AutoencoderKLCogVideoX, OurScheduler
+    mod.__version__ = "stand-in (oracle restatements)"
+    sys.modules["diffusers"] = mod
+
+
+def main(self_test: bool = False):
+    if self_test:
+        _install_standin()
     try:
         import diffusers  # noqa: F401
         from diffusers import AutoencoderKLCogVideoX, CogVideoXDPMScheduler, CogVideoXTransformer3DModel
@@ -91,9 +121,12 @@ def main():
         same_rng = torch.equal(torch.randn(3, generator=g1), torch.randn(3, generator=g2))
         print(f"scheduler n={n}: max|diff| = {err:.3e}, generators in lock-step: {same_rng}")
         ok &= err < 1e-5 and same_rng
-    print("ALL MATCH" if ok else "MISMATCH — see SURVEY.md Appendix A for the item to revisit")
+    print(("SELF-TEST PLUMBING OK (proves nothing about diffusers)" if self_test else "ALL MATCH") if ok else
+          "MISMATCH — see SURVEY.md Appendix A for the item to revisit")
+    if self_test:
+        sys.modules.pop("diffusers", None)
     return 0 if ok else 1
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    sys.exit(main(self_test="--self-test" in sys.argv))

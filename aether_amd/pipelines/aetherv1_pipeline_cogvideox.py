@@ -208,6 +208,10 @@ class AetherV1PipelineCogVideoX(_PipelineBase):
     # Extension: run the element-wise tail of every denoise step (P:877-916) as one HIP kernel (aether_dpm_step) when the scheduler is this
     # repo's CogVideoXDPMScheduler on an MI355X.  Bit-identical to the PyTorch sequence; False keeps the reference's op-by-op form.
     fuse_step_tail = True
+    # Extension: enqueue the two final VAE decodes (rgb, disparity: P:931,936) on two HIP streams so their small launches fill each other's
+    # gaps (measured −8.8 % for the pair at 41 x 480 x 720, profiles/r03_decode_pair.json); bit-identical outputs, one more VAE workspace.
+    # False = the reference's sequential calls.
+    decode_concurrently = True
 
     def __init__(self, tokenizer, text_encoder, vae, scheduler, transformer, empty_prompt_embeds: Optional[torch.Tensor] = None):
         super().__init__(tokenizer=tokenizer, text_encoder=text_encoder, vae=vae, scheduler=scheduler, transformer=transformer)
@@ -543,6 +547,10 @@ class AetherV1PipelineCogVideoX(_PipelineBase):
         if split:
             rgb_decoded, disparity_decoded = self._gather_pair(
                 self.decode_latents(rgb_latents if self._cfg_rank == 0 else disparity_latents)).split(1)
+        elif self.decode_concurrently and hasattr(self.vae, "decode_pair") and latents.is_cuda:
+            # the two decodes of P:931,936 on two HIP streams (aether_amd.vae.AetherVAE.decode_pair): same kernels, bit-identical results
+            inv = 1 / self.vae_scaling_factor_image
+            rgb_decoded, disparity_decoded = self.vae.decode_pair(inv * rgb_latents.permute(0, 2, 1, 3, 4), inv * disparity_latents.permute(0, 2, 1, 3, 4))
         else:
             rgb_decoded, disparity_decoded = self.decode_latents(rgb_latents), self.decode_latents(disparity_latents)
         disparity_video = disparity_decoded.mean(dim=1, keepdim=False)

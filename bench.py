@@ -170,6 +170,18 @@ def vae_leg(dev, reps=3):
         torch.cuda.synchronize()
         sec = e0.elapsed_time(e1) * 1e-3 / reps
         out[name] = {"seconds": sec, "algorithmic_tflop": tflop, "tflops": tflop / sec, "mfma_frac": tflop / sec / MFMA_PEAK_TFLOPS}
+    # the pipeline's two final decodes (rgb + disparity latents, P:931,936) as it issues them: on two HIP streams (AetherVAE.decode_pair)
+    z2 = torch.randn(1, 16, 11, 60, 90, generator=g, device=dev).to(torch.bfloat16)
+    for _ in range(3):
+        vae.decode_pair(z, z2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        vae.decode_pair(z, z2)
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / reps
+    out["decode_pair_two_streams"] = {"seconds": sec, "algorithmic_tflop": 2 * 369.0, "tflops": 2 * 369.0 / sec, "mfma_frac": 2 * 369.0 / sec / MFMA_PEAK_TFLOPS,
+                                      "note": "both decodes of one pipeline call, enqueued on two HIP streams; bit-identical to sequential calls"}
     del vae
     torch.cuda.empty_cache()
     return out

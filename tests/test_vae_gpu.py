@@ -441,3 +441,24 @@ def test_conv_tap_reuse_is_bit_identical(cuda, hip_lib, cin, cout, NB, T, H, W, 
     torch.cuda.synchronize()
     assert torch.isfinite(outs[0].float()).all() and float(outs[0].float().abs().max()) > 0.1
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_decode_pair_is_bit_identical(cuda, hip_lib):
+    """AetherVAE.decode_pair: the two final decodes of a pipeline call (rgb and disparity latents, P:931,936) enqueued on two HIP streams over one set
+    of packed weights (second C handle + workspace).  Same kernels in the same order within each decode: bit-identical to the sequential calls —
+    eagerly, on the captured hipGraphs, and again after the roles of the inputs are swapped."""
+    from aether_amd.vae import AetherVAE
+    kw = dict(block_out_channels=(64, 128, 128, 128), layers_per_block=1, sample_height=96, sample_width=240)
+    vae = AetherVAE(kw, device=cuda).init_random_weights(3)
+    vae.enable_tiling(); vae.enable_slicing()
+    g = torch.Generator(device=cuda).manual_seed(0)
+    za = torch.randn(1, 16, 5, 12, 30, generator=g, device=cuda).to(torch.bfloat16)
+    zb = torch.randn(1, 16, 5, 12, 30, generator=g, device=cuda).to(torch.bfloat16)
+    ref_a, ref_b = vae.decode(za).sample.clone(), vae.decode(zb).sample.clone()
+    for _ in range(3):                                     # eager first call, graph capture, replay
+        a, b = vae.decode_pair(za, zb)
+        torch.cuda.synchronize()
+        assert torch.equal(a, ref_a) and torch.equal(b, ref_b)
+    b2, a2 = vae.decode_pair(zb, za)
+    torch.cuda.synchronize()
+    assert torch.equal(a2, ref_a) and torch.equal(b2, ref_b)

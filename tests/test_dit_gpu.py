@@ -98,7 +98,7 @@ def test_dit_fused_qkv_epilogue_matches_the_two_pass_plan(cuda, hip_lib, case):
     e_a, e_b, e_16, d_ab = _rel(a, ref), _rel(b, ref), _rel(ref16, ref), _rel(b, a)
     print(f"{case}: two-pass {e_a:.3e}  fused epilogue {e_b:.3e}  bf16-oracle {e_16:.3e}  fused vs two-pass {d_ab:.3e}")
     # two bf16 evaluations of the same arithmetic differ by bf16 rounding decisions (switching the attention loop moves this output by
-    # 3e-3, tools/r03_diag_fuse_model.py): the plans must agree to within the bf16-oracle distance, and each must sit inside the usual bound
+    # 3e-3, tools/r03/r03_diag_fuse_model.py): the plans must agree to within the bf16-oracle distance, and each must sit inside the usual bound
     assert e_b < 1.5 * e_16 + 2e-3 and d_ab < e_16 + 1e-3
 
 

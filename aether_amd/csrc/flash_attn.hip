@@ -15,17 +15,18 @@
 //     the P·V MFMA (8 consecutive keys per 16-key slab) — no cross-lane movement of P.
 //   * V is consumed transposed (Vᵀ is produced once per layer by aether_qk_norm_rope), so its A-operand
 //     fragment is a plain 16-byte row read.
-//   * bounded-score fast path: at head_dim 64 the kernel is VALU-issue bound (≈5 VALU slots per score against
-//     16 MFMAs per 2048 scores), so the biggest lever is fewer VALU ops per score.  q and k are LayerNorm outputs,
-//     so |q·k| ≤ ‖q‖·max‖k‖ (Cauchy–Schwarz); aether_qk_norm_rope emits max‖k‖² per (batch, head, 64-key tile).  When that bound
-//     is ≤ 96 for every row of a wave, exp2(s) can neither overflow nor underflow in fp32/bf16 and soft-max is
-//     shift invariant, so the wave runs p = exp2(s) with NO running maximum, NO subtraction and NO rescale
-//     (1 v_exp + 1 v_add + ½ v_cvt_pk per score).  Otherwise (or when no bound is supplied) it runs the exact
-//     online soft-max with the conditional rescale.  The decision is per wave and wave-uniform.
+//   * soft-max: exact on every path, without bound tables (round 3).  Soft-max is invariant under any per-row shift; the running maximum only
+//     keeps exp2 in range.  The default loops run OPTIMISTICALLY with shift 0 and let the finished rows tell whether an exp2 left fp32's
+//     range (row sum not finite / below 2^-100, non-finite accumulator): the workgroup then votes and redoes its sweep on the conservative
+//     path, whose shift is a true score maximum and whose tiles are checked a posteriori (partial sum > 2^100 -> classic online step on the
+//     scores still held).  Details at FA_SHIFT_SPAN below and in include/aether_hip.h.  max||k||^2 (kmax2) is read only by the a-priori-
+//     guarded one-tile interleave (AETHER_ATTN_INTERLEAVE) and by round 1's software-pipelined kernel.
 //   * workgroups are remapped so that one XCD walks the query blocks of one (batch, head) consecutively:
 //     its K/V (3.9 MB at S = 15 076) stays in that XCD's 4 MiB L2.
 //
-// flash_attn_fwd_kernel: one barrier per KV tile, all waves in lock step, 128 VGPRs -> 16 waves per CU (TLP hides latency).
+// flash_attn_fwd_kernel: one barrier per KV tile, all waves in lock step, 128 VGPRs -> 16 waves per CU (TLP hides latency); the tile-pair
+//   pipeline (ILV = 2, the default) runs two tiles per iteration inside it.
+// flash_attn_rows64_kernel: 64 query rows per wave (K / V fragment reads shared by two MFMAs), two waves per SIMD — a measured variant.
 //   Default: one launch of 8-wave / 256-row workgroups (two per CU).  AETHER_ATTN_TAIL_SPLIT launches the first
 //   floor(nwg/512)*512 workgroups that way and the rest — a partly filled last round — as twice as many 4-wave / 128-row
 //   workgroups (four per CU); the "rounds" model promises 8 % for 2832 workgroups on 512 slots, the measurement gives < 1 %.
@@ -262,7 +263,7 @@ AE_DEV float fa_exp_tile(const f32x16 (&sc)[2], u32x4 (&pf)[2][2]) {
 // QREG (ILV = 2 only) = the tile-pair loop keeps the Q fragments in 16 registers (the optimistic sweep has no shift vector to hold) instead of
 // re-reading them from LDS: 8 of the 24 ds_read_b128 per tile go away.
 template <bool WIDE_STORE, int NW, int PRIO = 1, int ILV = 0, bool DOT2 = false, bool QREG = false>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))   // <= 128 VGPRs: 16 waves per CU
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 4 : 2, 4)))   // 8 waves: <= 128 VGPRs, 16 waves per CU
 void flash_attn_fwd_kernel(FlashArgs p) {
     // 2 x (K tile + V^T tile) + this workgroup's Q fragments (4 KiB per wave, lane-linear: conflict-free ds_read_b128).  Q lives in
     // LDS, not in 16 registers per lane: the registers hold the soft-max shift vector instead (see below) and the kernel stays
@@ -1159,7 +1160,9 @@ extern "C" int aether_flash_attn_fwd(const void* Qh, const void* Kh, const void*
         if (full > 0) {
             p.nwg = full; p.wg_first = 0;
             const int ilv = (flags & AETHER_ATTN_EXACT_MAX) ? 0 : (flags & AETHER_ATTN_PAIR_PIPELINE) ? 2 : (flags & AETHER_ATTN_INTERLEAVE) ? 1 : 0;
-            const bool dot2 = (flags & AETHER_ATTN_DOT2_SUM) != 0;
+            // row sums by v_dot2c: slower inside the tile-pair loop (-2 %), faster in the generic tile (+4 %: it also frees the registers the
+            // four add chains spill) — so the conservative path, whose hot loop IS the generic tile, always takes it
+            const bool dot2 = (flags & AETHER_ATTN_DOT2_SUM) != 0 || (ilv == 0 && (flags & AETHER_ATTN_EXACT_MAX) != 0);
             const bool qreg = (flags & AETHER_ATTN_QREG) != 0 && ilv == 2;
             auto launch = [&](auto W, auto I, auto D) {
                 constexpr int ILV_ = decltype(I)::value;

@@ -144,7 +144,7 @@ class AetherVAE:
         self._taps: Dict[tuple, torch.Tensor] = {}
         self._splitk_ws: Optional[torch.Tensor] = None       # fp32 scratch for split-K partial tiles (allocated on first use)
         self.splitk_ws_bytes = 96 << 20
-        self.tap_reuse_max_waste = 1.06                       # padded-plane / output-plane ratio up to which the tap-reuse conv runs (0: never)
+        self._tap_reuse_max_waste = 1.06                      # padded-plane / output-plane ratio up to which the tap-reuse conv runs (0: never)
         self._loaded = False
         # encode()/decode() are ONE C call each (aether_vae_encode / aether_vae_decode: the launch plan lives in csrc/vae_plan.hip).
         # use_c_plan = False walks the same graph from Python through the per-kernel entry points (tests, A/B: bit-identical).
@@ -171,6 +171,20 @@ class AetherVAE:
 
     def eval(self):
         return self
+
+    @property
+    def tap_reuse_max_waste(self) -> float:
+        return self._tap_reuse_max_waste
+
+    @tap_reuse_max_waste.setter
+    def tap_reuse_max_waste(self, value: float):
+        """The C launch plan copies this tunable into its handle at registration: changing it after the weights are loaded re-registers the plan
+        (new handle, workspace pool and hipGraphs start over), so the C plan and the Python walk can never run with different settings."""
+        self._tap_reuse_max_waste = float(value)
+        if getattr(self, "_loaded", False):
+            self._register_c_plan()
+            if getattr(self, "_twin", None) is not None:
+                self._twin = None
 
     def enable_tiling(self):
         self.use_tiling = True

@@ -373,10 +373,10 @@ def test_flash_attention_bound_gate(cuda, hip_lib, flags):
     out = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags, kmax2=kmax2.to(cuda))
     torch.cuda.synchronize()
     _bf16_close(out, ref.transpose(1, 2).reshape(1, 640, 128), f"flash bound gate flags={flags}", rel=1.5e-2, max_ulp_frac=4.0)
-    # AETHER_ATTN_EXACT_MAX = the conservative path (true-maximum shift, no bound table): what every variant but the optimistic
-    # tile-pair pipeline (512) runs when no bound is supplied — bit-identical then; and exact for 512 as well
+    # AETHER_ATTN_EXACT_MAX = the conservative path: generic tiles (true-maximum shift, a-posteriori check, no bound table) with the row
+    # sums by v_dot2c — what every variant but the optimistic sweeps (512, 8192) runs when no bound is supplied and 2048 is set: bit-identical
     a = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags | 32, kmax2=kmax2.to(cuda))
-    b = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags, kmax2=None)
+    b = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags | 2048, kmax2=None)
     torch.cuda.synchronize()
     if not flags & (512 | 8192):
         assert torch.equal(a, b)

@@ -184,3 +184,53 @@ def test_check_against_diffusers_self_test(capsys):
     out = capsys.readouterr().out
     assert "transformer max|diff| = 0.000e+00" in out and "SELF-TEST PLUMBING OK" in out and "generators in lock-step: True" in out
     assert "diffusers" not in sys.modules or getattr(sys.modules["diffusers"], "__version__", "").startswith("stand-in") is False
+
+
+@pytest.mark.parametrize("nb,steps", [(1, 4), (2, 50)])
+def test_fused_step_arithmetic_restated_on_the_cpu(nb, steps):
+    """The op sequence aether_dpm_step (csrc/sampler.hip) implements, restated op by op in torch on the CPU from the scalars of
+    `CogVideoXDPMScheduler._coefficients`, against `scheduler.step` fed the way the pipeline feeds it (P:877-916) over a whole schedule: bit-identical
+    latents and x0 at every step — which pins the decomposition (coefficients, operation order, which draw is used, where bf16 roundings fall).
+    One rounding differs between PyTorch's two back ends and is restated here the CPU way: a float64 scalar times a bf16 TENSOR rounds the
+    scalar to bf16 first on the CPU, to fp32 on CUDA (measured: 14 % of the products differ in the last bit).  The HIP kernel follows CUDA —
+    the back end the reference runs on — and is compared with the CUDA sequence on the GPU (tests/test_kernels_gpu.py, bit-identical)."""
+    import torch
+    from aether_amd.scheduler import CogVideoXDPMScheduler
+    f32 = lambda v: torch.as_tensor(v, dtype=torch.float64).to(torch.float32)  # noqa: E731  scalar operand as PyTorch rounds it
+    bf = lambda x: x.to(torch.bfloat16).to(torch.float32)  # noqa: E731          one bf16 rounding
+    sbf = lambda v: bf(f32(v))  # noqa: E731                                      scalar operand of a bf16-tensor op on the CPU back end
+    shape = (1, 2, 56, 6, 8)
+    g = torch.Generator().manual_seed(5)
+    lat0 = torch.randn(shape, generator=g).to(torch.bfloat16)
+    preds = [(torch.randn((nb,) + shape[1:], generator=g) * 1.3).to(torch.bfloat16) for _ in range(steps)]
+    scale = 3.7
+    sched = CogVideoXDPMScheduler()
+    sched.set_timesteps(steps)
+    ts = sched.timesteps.tolist()
+    ga, gb = torch.Generator().manual_seed(11), torch.Generator().manual_seed(11)
+    lat_a, old_a = lat0.clone(), None
+    lat_b, old_b = lat0.clone(), None
+    for i, t in enumerate(ts):
+        tb = ts[i - 1] if i > 0 else None
+        # (a) the reference sequence
+        npred = preds[i].float()
+        if nb == 2:
+            u, c = npred.chunk(2)
+            npred = u + scale * (c - u)
+        lat_a, old_a = sched.step(npred, old_a, t, tb, lat_a, generator=ga, return_dict=False)
+        lat_a = lat_a.to(torch.bfloat16)
+        # (b) what the kernel computes
+        k = sched._coefficients(t, tb, old_b is not None)
+        noise = torch.randn(shape, generator=gb, dtype=torch.bfloat16)
+        if k["second"]:
+            noise = torch.randn(shape, generator=gb, dtype=torch.bfloat16)
+        s = lat_b.float()
+        mo = preds[i][:1].float()
+        if nb == 2:
+            mo = mo + f32(scale) * (preds[i][1:].float() - mo)
+        x0 = bf(sbf(k["a_sqrt"]) * s) - f32(k["b_sqrt"]) * mo
+        d = f32(k["m3"]) * x0 - f32(k["m4"]) * old_b if k["second"] else x0
+        prev = (bf(sbf(k["m1"]) * s) - f32(k["m2"]) * d) + bf(sbf(k["m_noise"]) * noise.float())
+        lat_b, old_b = prev.to(torch.bfloat16), x0
+        assert torch.equal(lat_a, lat_b), f"latents differ at step {i}"
+        assert torch.equal(old_a, old_b), f"x0 differs at step {i}"

@@ -234,3 +234,28 @@ def test_fused_step_arithmetic_restated_on_the_cpu(nb, steps):
         lat_b, old_b = prev.to(torch.bfloat16), x0
         assert torch.equal(lat_a, lat_b), f"latents differ at step {i}"
         assert torch.equal(old_a, old_b), f"x0 differs at step {i}"
+
+
+def test_fullsize_cases_reproduce_the_fixture_inputs():
+    """tools/fullsize_cases.py builds the inputs of the full-depth fixtures from seeds (CPU generators, numpy): what it builds HERE must be what
+    tools/make_fullsize_golden.py saw when it wrote tests/golden/fullsize_*.npz (the GPU tests rebuild them once more on the GPU box)."""
+    import json
+    import os
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fullsize_cases as fc
+    meta = json.loads(str(np.load(os.path.join(fc.GOLDEN_DIR, "fullsize_dit.npz"))["meta"]))
+    hidden, text, t = fc.dit_inputs()
+    assert hidden.shape == (1, 11, 96, 60, 90) and text.shape == (1, 226, 4096) and int(t[0]) == meta["timestep"] == 999
+    assert abs(float(hidden.float().sum()) - meta["input_sum"]) < 1e-3 * max(1.0, abs(meta["input_sum"]))
+    assert meta["layers"] == 42 and meta["dit_seed"] == fc.DIT_SEED and meta["input_seed"] == fc.DIT_INPUT_SEED
+    z = np.load(os.path.join(fc.GOLDEN_DIR, "fullsize_clip.npz"))
+    cm = json.loads(str(z["meta"]))
+    video = fc.clip_video()
+    assert video.shape == (41, 480, 720, 3) and abs(float(video.astype(np.float64).sum()) - cm["video_sum"]) < 1e-6 * cm["video_sum"]
+    assert cm["steps"] == fc.CLIP_STEPS == 4 and cm["clip_seed"] == fc.CLIP_SEED and cm["vae_seed"] == fc.VAE_SEED
+    assert z["final_latents_bits"].shape == (1, 11, 56, 60, 90) and z["posterior_mean"].shape == (1, 16, 11, 60, 90)
+    assert z["rgb_s8"].shape == (41, 480 // fc.DEC_STRIDE, 720 // fc.DEC_STRIDE, 3)
+    lat = fc.from_bf16_bits(z["final_latents_bits"]).float()
+    assert bool(np.isfinite(lat.numpy()).all()) and 1.0 < float(lat.abs().max()) < 20.0

@@ -15,20 +15,9 @@ AETHER_EPI_BIAS = 0
 AETHER_EPI_BIAS_GELU = 1
 AETHER_EPI_BIAS_GATE_RES = 2
 AETHER_GEMM_WIDE_STORE = 1
-AETHER_GEMM_PINGPONG = 4      # ping-pong main loop (see include/aether_hip.h)
-AETHER_GEMM_PINGPONG2 = 8
-AETHER_GEMM_PERSISTENT = 32768  # persistent grid (236 workgroups for the DiT shapes, whole tiles each, no tail launch)
+AETHER_GEMM_SPLIT_LONE_TAIL = 2   # a launch of 64..128 tiles with K >= 2048 also splits its K loop (fused-qkv remainder only)
 AETHER_DIT_FUSE_QKV_PREP = 65536  # aether_dit_forward: q/k norm + RoPE + V transpose in the qkv GEMM's epilogue
-AETHER_GEMM_4WAVE = 1024      # four-wave main loop (one wave per SIMD, in-wave interleaving)
-AETHER_ATTN_PIPELINED = 16    # attention: software-pipelined kernel
 AETHER_ATTN_EXACT_MAX = 32    # attention: conservative path only (true-maximum shift from tile 0, a-posteriori check per tile)
-AETHER_ATTN_TAIL_SPLIT = 64   # attention: the partly filled last round runs as 128-row workgroups (second launch)
-AETHER_ATTN_INTERLEAVE = 256  # attention: steady-state tiles interleave soft-max VALU with the wave's own MFMAs
-AETHER_ATTN_PAIR_PIPELINE = 512   # attention: two tiles per iteration (soft-max spread over 24 of 32 MFMAs), optimistic shift 0 + redo
-AETHER_ATTN_ROWS64 = 8192         # attention: 64 query rows per wave (K/V fragment reads shared by two MFMAs), 2 waves per SIMD
-AETHER_ATTN_WG512 = 16384         # attention (with ROWS64): 512-row workgroups of 8 waves, one per CU
-AETHER_ATTN_QREG = 4096           # attention: Q fragments in registers inside the tile-pair loop
-AETHER_ATTN_DOT2_SUM = 2048       # attention: row sums from the rounded bf16 P pairs by v_dot2c_f32_bf16
 AETHER_CONV_TAP_REUSE = 128   # conv: K order is (dt, dh, channel block, dw) -> the tap-reuse kernel may be used
 ATTN_Q_SCALE = 0.125 * 1.4426950408889634   # softmax scale x log2(e): the attention kernel works in the log2 domain
 PROF_CLASSES = ["other", "layernorm", "gemm_qkv", "qk_norm_rope", "attention", "gemm_out", "gemm_ff1", "gemm_ff2"]
@@ -64,11 +53,11 @@ SIGNATURES = {
     "aether_timestep_sinusoid": (_i, [_fp, _i, _i, _fp, _vp]),
     "aether_patchify": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "aether_unpatchify": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "aether_qk_norm_rope": (_i, [_vp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _f, _fp, _fp, _f, _vp, _vp, _vp, _i, _fp, _vp]),
+    "aether_qk_norm_rope": (_i, [_vp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _f, _fp, _fp, _f, _vp, _vp, _vp, _i, _vp]),
     "aether_qk_norm_rope_tail": (_i, [_vp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _f, _fp, _fp, _f, _vp, _vp, _vp, _i, _i, _vp]),
     "aether_vt_pad_zero": (_i, [_vp, _i, _i, _i, _vp]),
     "aether_gemm_qkv_prep": (_i, [_vp, _i, _vp, _i, _fp, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _f, _fp, _fp, _f, _vp, _vp, _vp, _i, _i, _vp]),
-    "aether_flash_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _fp, _i, _vp]),
+    "aether_flash_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "aether_dpm_step": (_i, [_vp, _i, _f, _vp, _fp, _vp, _f, _f, _f, _f, _f, _f, _f, _fp, _fp, _vp, C.c_long, _vp]),
     "aether_conv_gemm_bf16": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _fp, _vp, _i, _fp, _sz, _i, _vp]),
     "aether_im2col_first": (_i, [_vp, C.c_long, C.c_long, C.c_long, C.c_long, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),

@@ -48,7 +48,7 @@ constexpr size_t kSplitKBytes = (size_t)256 * 256 * 256 * sizeof(float);   // fp
 struct Plan {
     int D, FF, Nt, Nv, S, M, Spad, Kp, Np, Nmod, PH, PW;
     size_t off_x, off_xn, off_qkv, off_qh, off_kh, off_vt, off_attn, off_ff, off_patch, off_tsin, off_t1, off_temb,
-        off_mod, off_proj, off_kmax, off_splitk, total;
+        off_mod, off_proj, off_splitk, total;
 };
 
 Plan make_plan(const AetherDitConfig& c, int B, int F, int H, int W) {
@@ -81,7 +81,6 @@ Plan make_plan(const AetherDitConfig& c, int B, int F, int H, int W) {
     p.off_temb = take((size_t)B * c.time_embed_dim * 4);
     p.off_mod = take((size_t)B * p.Nmod * 4);
     p.off_proj = take((size_t)B * p.Nv * p.Np * 2);
-    p.off_kmax = take((size_t)B * c.num_heads * (p.Spad / 64) * 4);
     p.off_splitk = take(kSplitKBytes);
     p.total = o;
     return p;
@@ -219,7 +218,7 @@ extern "C" int aether_dit_forward(AetherDit* h, const void* hidden, const void* 
     char* qh = ws + p.off_qh; char* kh = ws + p.off_kh; char* vt = ws + p.off_vt;
     char* attn = ws + p.off_attn; char* ff = ws + p.off_ff; char* patch = ws + p.off_patch;
     float* tsin = (float*)(ws + p.off_tsin); float* t1 = (float*)(ws + p.off_t1); float* temb = (float*)(ws + p.off_temb);
-    float* mod = (float*)(ws + p.off_mod); char* proj = ws + p.off_proj; float* kmax = (float*)(ws + p.off_kmax); float* skws = (float*)(ws + p.off_splitk);
+    float* mod = (float*)(ws + p.off_mod); char* proj = ws + p.off_proj; float* skws = (float*)(ws + p.off_splitk);
     const int D = p.D, FF = p.FF, S = p.S, M = p.M, Nt = p.Nt, Nv = p.Nv, L = c.num_layers, fl = c.flags;
     auto W_ = [&](const char* n) { return (const char*)h->w[n]; };
     auto Wf = [&](const char* n) { return (const float*)h->w[n]; };
@@ -244,13 +243,10 @@ extern "C" int aether_dit_forward(AetherDit* h, const void* hidden, const void* 
 
     // ---- transformer blocks ----------------------------------------------------------------------
     // softmax scale 1/sqrt(64) and log2(e) folded into Q in fp32 before its single rounding to bf16: scores arrive in
-    // the log2 domain.  kmax receives max ||k||^2 per (batch, head, 64-key tile) of the current layer (bounded-score soft-max path).
+    // the log2 domain.
     const float q_scale = 0.125f * 1.4426950408889634f;
-    // the per-tile bound table is read only by the a-priori-guarded / round-1 attention paths; the default (optimistic) sweeps need none
-    const bool need_kmax = (fl & (AETHER_ATTN_INTERLEAVE | AETHER_ATTN_PIPELINED)) != 0 && !(fl & AETHER_ATTN_EXACT_MAX);
-    if (!need_kmax) kmax = nullptr;
-    // q/k norm + RoPE + V^T as the qkv GEMM's epilogue (AETHER_DIT_FUSE_QKV_PREP); needs the 256-wide head grouping and no bound table
-    const bool fuse_qkv = (fl & AETHER_DIT_FUSE_QKV_PREP) != 0 && !need_kmax && D % 256 == 0 && !(fl & AETHER_GEMM_4WAVE);
+    // q/k norm + RoPE + V^T as the qkv GEMM's epilogue (AETHER_DIT_FUSE_QKV_PREP); needs the 256-wide head grouping
+    const bool fuse_qkv = (fl & AETHER_DIT_FUSE_QKV_PREP) != 0 && D % 256 == 0;
     int rows_f = M;
     if (fuse_qkv) {
         if (B == 1) rows_f = std::min(M, fused_row_tiles((M + 255) / 256, 3 * D / 256) * 256);
@@ -270,7 +266,7 @@ extern "C" int aether_dit_forward(AetherDit* h, const void* hidden, const void* 
                 if (rc || rows_f == M) return rc;
                 return aether_gemm_bf16(xn + (size_t)rows_f * D * 2, D, W_("qkv_w") + (size_t)i * 3 * D * D * 2, D, qkv + (size_t)rows_f * 3 * D * 2, 3 * D,
                                         M - rows_f, 3 * D, D, Wf("qkv_b") + (size_t)i * 3 * D, AETHER_EPI_BIAS, nullptr, 0, nullptr, nullptr, 0, 0, 0, skws,
-                                        kSplitKBytes, fl, stream);
+                                        kSplitKBytes, fl | AETHER_GEMM_SPLIT_LONE_TAIL, stream);
             };
             AE_RUN(AETHER_PROF_GEMM_QKV, fused());
             if (rows_f < M)
@@ -280,9 +276,9 @@ extern "C" int aether_dit_forward(AetherDit* h, const void* hidden, const void* 
             AE_RUN(AETHER_PROF_GEMM_QKV, aether_gemm_bf16(xn, D, W_("qkv_w") + (size_t)i * 3 * D * D * 2, D, qkv, 3 * D, M, 3 * D, D,
                                     Wf("qkv_b") + (size_t)i * 3 * D, AETHER_EPI_BIAS, nullptr, 0, nullptr, nullptr, 0, 0, 0, skws, kSplitKBytes, fl, stream));
             AE_RUN(AETHER_PROF_QKROPE, aether_qk_norm_rope(qkv, B, S, c.num_heads, Nt, Wf("qn_w") + i * 64, Wf("qn_b") + i * 64, Wf("kn_w") + i * 64,
-                                       Wf("kn_b") + i * 64, c.qk_norm_eps, rope_cos, rope_sin, q_scale, qh, kh, vt, p.Spad, kmax, stream));
+                                       Wf("kn_b") + i * 64, c.qk_norm_eps, rope_cos, rope_sin, q_scale, qh, kh, vt, p.Spad, stream));
         }
-        AE_RUN(AETHER_PROF_ATTN, aether_flash_attn_fwd(qh, kh, vt, attn, B, c.num_heads, S, p.Spad, kmax, fl, stream));
+        AE_RUN(AETHER_PROF_ATTN, aether_flash_attn_fwd(qh, kh, vt, attn, B, c.num_heads, S, p.Spad, fl, stream));
         AE_RUN(AETHER_PROF_GEMM_O, aether_gemm_bf16(attn, D, W_("o_w") + (size_t)i * D * D * 2, D, x, D, M, D, D, Wf("o_b") + (size_t)i * D,
                                 AETHER_EPI_BIAS_GATE_RES, x, D, m1 + 2 * D, m1 + 5 * D, p.Nmod, S, Nt, skws, kSplitKBytes, fl, stream));
         AE_RUN(AETHER_PROF_LN, aether_layernorm_modulate(x, D, xn, D, M, D, c.norm_eps, Wf("ln2_w") + (size_t)i * D, Wf("ln2_b") + (size_t)i * D,

@@ -185,7 +185,7 @@ __global__ void unpatchify_kernel(const unsigned short* __restrict__ Y, int ldy,
 
 // ------------------------------------------------------------------------------------------------
 // ONE pass over the fused qkv projection: q/k LayerNorm(64) + 3-D RoPE (+ softmax scale on q) -> head-major Qh / Kh,
-// V -> V^T (through LDS), max ||k||^2 of the tile -> kmax2.  One workgroup per (64-token tile, batch·head): it reads the
+// V -> V^T (through LDS).  One workgroup per (64-token tile, batch·head): it reads the
 // three 64 x 64 blocks of its head out of the [B, S, 3·H·64] projection (128-byte row segments) and writes three 8 KiB
 // tiles.  Round 1 did this in two kernels (q/k rows, then V transpose + a re-read of Kh for the norms: 648 MB of traffic per
 // layer at S = 15 076); fused it moves each element once in, once out (554 MB).
@@ -194,9 +194,8 @@ struct QkArgs {
     const bf16_t* qkv; int S, H, n_text, Spad;
     const float* qn_w; const float* qn_b; const float* kn_w; const float* kn_b; float eps;
     const float* cos_t; const float* sin_t; float q_scale;
-    bf16_t* Qh; bf16_t* Kh; unsigned short* Vt; float* kmax2;
+    bf16_t* Qh; bf16_t* Kh; unsigned short* Vt;
     int tile_first;       // first 64-token tile of this launch (the fused qkv GEMM epilogue may have done the tiles before it)
-    int ntiles_all;       // Spad / 64 (row length of kmax2)
 };
 
 // LayerNorm(64) of one head row spread over 8 lanes (8 values each) + affine + RoPE (adjacent pairs) + scale, rounded to bf16;
@@ -230,7 +229,6 @@ AE_DEV uint4 qk_row(const u16x8 raw, const f32x4 (&nw)[2], const f32x4 (&nb)[2],
 
 __global__ __launch_bounds__(256) void qkv_prepare_kernel(QkArgs p) {
     __shared__ unsigned short tile[64][66];
-    __shared__ float wmax[4];
     // head fastest in the grid: the workgroups running together cover the same 64 token rows across all heads, i.e. whole
     // contiguous 18 KiB rows of the projection between them
     const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
@@ -265,7 +263,6 @@ __global__ __launch_bounds__(256) void qkv_prepare_kernel(QkArgs p) {
         qw[j] = *(const f32x4*)(p.qn_w + ch * 8 + 4 * j); qb[j] = *(const f32x4*)(p.qn_b + ch * 8 + 4 * j);
         kw[j] = *(const f32x4*)(p.kn_w + ch * 8 + 4 * j); kb[j] = *(const f32x4*)(p.kn_b + ch * 8 + 4 * j);
     }
-    float kmx = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int sl = (tid >> 3) + 32 * i;
@@ -279,28 +276,8 @@ __global__ __launch_bounds__(256) void qkv_prepare_kernel(QkArgs p) {
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) tile[ch * 8 + e][sl] = ok[i] ? rv[i][e] : (unsigned short)0;
-        // ||k||^2 of the rounded bf16 key (what attention reads): the 64 elements of a token sit in the 8 lanes sharing `sl`
-        float n2 = 0.f;
-        if (ok[i] && p.kmax2 != nullptr) {
-            const unsigned kwd[4] = {k.x, k.y, k.z, k.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float lo = __uint_as_float(kwd[e] << 16), hi2 = __uint_as_float(kwd[e] & 0xffff0000u);
-                n2 += lo * lo; n2 += hi2 * hi2;
-            }
-        }
-        if (p.kmax2 != nullptr) {
-            n2 += __shfl_xor(n2, 1, 64); n2 += __shfl_xor(n2, 2, 64); n2 += __shfl_xor(n2, 4, 64);
-            kmx = fmaxf(kmx, n2);
-        }
-    }
-    if (p.kmax2 != nullptr) {
-        kmx = wave_max(kmx);
-        if ((tid & 63) == 0) wmax[tid >> 6] = kmx;
     }
     __syncthreads();
-    if (p.kmax2 != nullptr && tid == 0)
-        p.kmax2[(size_t)bh * p.ntiles_all + tile_idx] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int piece = tid + i * 256;          // d = piece/8, token chunk = piece%8; pad columns (s >= S) are zero
@@ -384,13 +361,13 @@ extern "C" int aether_unpatchify(const void* Y, int ldy, void* out, int B, int F
 
 extern "C" int aether_qk_norm_rope(const void* qkv, int B, int S, int H, int n_text, const float* qn_w, const float* qn_b,
                                    const float* kn_w, const float* kn_b, float eps, const float* cos_t, const float* sin_t,
-                                   float q_scale, void* Qh, void* Kh, void* Vt, int Spad, float* kmax2, void* stream) {
+                                   float q_scale, void* Qh, void* Kh, void* Vt, int Spad, void* stream) {
     if (!qkv || !Qh || !Kh || !Vt || !qn_w || !qn_b || !kn_w || !kn_b) return aether_set_error(AETHER_ERR_ARG, "qk_norm_rope: null pointer");
     if (B <= 0 || S <= 0 || H <= 0 || n_text < 0 || n_text > S) return aether_set_error(AETHER_ERR_SHAPE, "qk_norm_rope: bad shape");
     if (n_text < S && (!cos_t || !sin_t)) return aether_set_error(AETHER_ERR_ARG, "qk_norm_rope: rope tables required");
     if (Spad % 64 != 0 || Spad < S) return aether_set_error(AETHER_ERR_SHAPE, "qk_norm_rope: Spad must be roundup(S,64)");
     QkArgs p{(const bf16_t*)qkv, S, H, n_text, Spad, qn_w, qn_b, kn_w, kn_b, eps, cos_t, sin_t, q_scale, (bf16_t*)Qh, (bf16_t*)Kh,
-             (unsigned short*)Vt, kmax2, 0, Spad / 64};
+             (unsigned short*)Vt, 0};
     hipLaunchKernelGGL(qkv_prepare_kernel, dim3(B * H, Spad / 64), dim3(256), 0, AE_STREAM, p);
     return aether_check_launch("qkv_prepare");
 }
@@ -406,7 +383,7 @@ extern "C" int aether_qk_norm_rope_tail(const void* qkv, int B, int S, int H, in
     if (Spad % 64 != 0 || Spad < S || first_token < 0 || first_token % 64 != 0 || first_token >= Spad)
         return aether_set_error(AETHER_ERR_SHAPE, "qk_norm_rope_tail: Spad must be roundup(S,64), first_token a multiple of 64 below it");
     QkArgs p{(const bf16_t*)qkv, S, H, n_text, Spad, qn_w, qn_b, kn_w, kn_b, eps, cos_t, sin_t, q_scale, (bf16_t*)Qh, (bf16_t*)Kh,
-             (unsigned short*)Vt, nullptr, first_token / 64, Spad / 64};
+             (unsigned short*)Vt, first_token / 64};
     hipLaunchKernelGGL(qkv_prepare_kernel, dim3(B * H, (Spad - first_token) / 64), dim3(256), 0, AE_STREAM, p);
     return aether_check_launch("qkv_prepare (tail)");
 }

@@ -19,18 +19,15 @@
 //     keeps exp2 in range.  The default loops run OPTIMISTICALLY with shift 0 and let the finished rows tell whether an exp2 left fp32's
 //     range (row sum not finite / below 2^-100, non-finite accumulator): the workgroup then votes and redoes its sweep on the conservative
 //     path, whose shift is a true score maximum and whose tiles are checked a posteriori (partial sum > 2^100 -> classic online step on the
-//     scores still held).  Details at FA_SHIFT_SPAN below and in include/aether_hip.h.  max||k||^2 (kmax2) is read only by the a-priori-
-//     guarded one-tile interleave (AETHER_ATTN_INTERLEAVE) and by round 1's software-pipelined kernel.
+//     scores still held).  Details at FA_SHIFT_SPAN below and in include/aether_hip.h.
 //   * workgroups are remapped so that one XCD walks the query blocks of one (batch, head) consecutively:
 //     its K/V (3.9 MB at S = 15 076) stays in that XCD's 4 MiB L2.
 //
-// flash_attn_fwd_kernel: one barrier per KV tile, all waves in lock step, 128 VGPRs -> 16 waves per CU (TLP hides latency); the tile-pair
-//   pipeline (ILV = 2, the default) runs two tiles per iteration inside it.
-// flash_attn_rows64_kernel: 64 query rows per wave (K / V fragment reads shared by two MFMAs), two waves per SIMD — a measured variant.
-//   Default: one launch of 8-wave / 256-row workgroups (two per CU).  AETHER_ATTN_TAIL_SPLIT launches the first
-//   floor(nwg/512)*512 workgroups that way and the rest — a partly filled last round — as twice as many 4-wave / 128-row
-//   workgroups (four per CU); the "rounds" model promises 8 % for 2832 workgroups on 512 slots, the measurement gives < 1 %.
-// flash_attn_swp_kernel: software-pipelined variant (AETHER_ATTN_PIPELINED), see below.
+// flash_attn_fwd_kernel: one barrier per KV tile, all waves in lock step, 128 VGPRs -> 16 waves per CU (TLP hides latency).  PAIR (the
+//   default) runs two tiles per iteration with the soft-max of every 32-key half spread over its neighbours' MFMAs and the Q fragments in
+//   registers; !PAIR (AETHER_ATTN_EXACT_MAX) is the conservative path alone.  The variants measured and retired in rounds 1-3 (software-
+//   pipelined one-workgroup-per-CU kernel, a-priori-guarded one-tile interleave with a max||k||^2 table, 64 query rows per wave, 128-row
+//   tail workgroups, Q fragments from LDS) are recorded in profiles/r0{1,2,3}_attn_variants*.
 #include <type_traits>
 #include <utility>
 #include "common.hpp"
@@ -43,18 +40,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int FA_QBLK = 256, FA_KVBLK = 64, FA_D = 64;
 constexpr int FA_TILE = FA_KVBLK * FA_D * 2;  // 8 KiB (K tile) == 8 KiB (Vᵀ tile)
 constexpr int FA_BUF = 2 * FA_TILE;
-constexpr float FA_FAST_BOUND2 = 96.f * 96.f;  // (‖q‖·max‖k‖)² limit of the bounded-score path: |s| <= 96 keeps every p = exp2(s) a normal
-                                               // fp32 / bf16 number (2^-96 .. 2^96) and every sum below 2^96 · S · max|v| << 2^127
-constexpr float FA_BOUND_SLACK = 1.02f;        // covers the bf16 rounding of k after its norm was taken (2^-8 rel.)
 
 struct FlashArgs {
     const bf16_t* Q; const bf16_t* K; const bf16_t* Vt; bf16_t* O;
-    const float* kmax2;   // [B*H][Spad/64] upper bound of ‖k‖² per (batch, head, 64-key tile), or null
-    int H, S, Spad, nqb, nwg;   // nqb: query blocks per head at THIS launch's block size; nwg: workgroups of this launch
-    int wg_first;               // index of this launch's first workgroup in (head, query block) order
+    int H, S, Spad, nqb, nwg;   // nqb: 256-row query blocks per head; nwg: workgroups of the launch
 };
 
-// ---- pieces shared by the two kernels ---------------------------------------------------------------------------
+// ---- lane geometry -----------------------------------------------------------------------------------------------
 struct FaLane {
     int lane, wave, hi, l32;
     int koff[4];      // K fragment byte offsets inside a tile (+ t*4096)
@@ -87,60 +79,6 @@ AE_DEV void fa_mask_tail(f32x16 (&sc)[2], int j, int hi, int S) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             if (kb + 32 * t + 16 * (r >> 3) + (r & 7) >= S) sc[t][r] = -INFINITY;
-}
-
-// soft-max of one 32 x 64 score tile held as sc[2] -> bf16 P fragments pf[t][s] (B operand of P·V).
-// FAST: p = exp2(s), no maximum.  Otherwise exact online soft-max: m_run/l_run/o are rescaled when a row maximum grew.
-template <bool FAST>
-AE_DEV void fa_softmax(const f32x16 (&sc)[2], bf16x8 (&pf)[2][2], f32x16 (&o)[2], float& m_run, float& l_run) {
-    float shift = 0.f;
-    if (!FAST) {
-        float mx = sc[0][0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[0][r]);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[1][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        if (__any(m_new > m_run)) {
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // 0 on the first tile (m_run = -inf)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
-            l_run *= alpha;
-            m_run = m_new;
-        }
-        shift = m_run;
-    }
-    float psum[4] = {0.f, 0.f, 0.f, 0.f};   // four independent add chains
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            float pv[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                pv[e] = __builtin_amdgcn_exp2f(FAST ? sc[t][8 * s + e] : sc[t][8 * s + e] - shift);
-                psum[e & 3] += pv[e];
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) pf[t][s][e] = (__bf16)pv[e];
-        }
-    l_run += (psum[0] + psum[1]) + (psum[2] + psum[3]);
-}
-
-// per-wave decision: every row of this wave has (‖q‖·max‖k‖)² within the bounded-score limit
-AE_DEV bool fa_fast_ok(const bf16x8 (&qf)[4], const float* kmax2, int bh, int ntiles) {
-    if (kmax2 == nullptr) return false;
-    float km = 0.f;
-    for (int i = threadIdx.x & 63; i < ntiles; i += 64) km = fmaxf(km, kmax2[(size_t)bh * ntiles + i]);
-    km = wave_max(km);
-    float qn2 = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { const float q = (float)qf[ks][e]; qn2 += q * q; }
-    qn2 += __shfl_xor(qn2, 32, 64);
-    return __all(qn2 * km * FA_BOUND_SLACK <= FA_FAST_BOUND2) != 0;
 }
 
 // epilogue: O[q][h*64 + d], d = 32dt + 8(r>>2) + 4hi + (r&3)
@@ -179,32 +117,17 @@ template <int I> using ic = std::integral_constant<int, I>;
 template <class F, int... Is> AE_DEV void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(ic<Is>{}), ...); }
 template <int N, class F> AE_DEV void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
-// ---- guarded static shift (the lock-step kernel's soft-max; exact, shift-invariant) -----------------------------------
-// Soft-max is invariant under ANY per-row shift c:  o = Σ exp2(s−c)·v / Σ exp2(s−c).  The online algorithm uses c = the
-// running maximum only to keep exp2 in range.  Here the shift of a row is a value m that is a TRUE score maximum of the tiles
-// on which it was last refreshed (so the row's largest term is ≥ 1: no underflow of the sums), and a tile may be
-// exponentiated against the un-refreshed m — no maximum, no subtraction (m enters through the C operand of the first QKᵀ
-// MFMA: sc = K·Qᵀ − m for free), no rescale — whenever a cheap bound proves exp2 cannot overflow on it:
-//     |s| ≤ ‖q‖·max_tile‖k‖  (Cauchy–Schwarz; max‖k‖² per 64-key tile comes from aether_qk_norm_rope)
-//     ‖q‖²·max‖k‖² ≤ (m + FA_SHIFT_SPAN)²  with  m + FA_SHIFT_SPAN > 0   ⇒   s − m ≤ FA_SHIFT_SPAN  for every key of the tile.
-// p ≤ 2^100 is a normal fp32 / bf16 number and the sums stay below 2^100 · S · max|v| < 2^127 for S·max|v| < 2^27.  A tile that fails the test (the
-// first tile of every row, and any tile whose keys could exceed the span) takes the refresh path: tile maximum, m ← max,
-// conditional rescale of o and l — the classic online step.  The choice is per wave and per tile, wave-uniform, and changes
-// only speed: results are those of an exact soft-max in fp32 either way.  AETHER_ATTN_EXACT_MAX (no bound table) refreshes on
-// every tile.
+// ---- shift-invariant soft-max --------------------------------------------------------------------------------------------
+// Soft-max is invariant under ANY per-row shift c:  o = Σ exp2(s−c)·v / Σ exp2(s−c).  The online algorithm uses c = the running
+// maximum only to keep exp2 in range.  On the conservative path the shift of a row is a value m that is a TRUE score maximum of the
+// tiles on which it was last refreshed (so the row's largest term is ≥ 1: no underflow of the sums); a tile is exponentiated against
+// the standing m — no maximum, no subtraction (m enters through the C operand of the first QKᵀ MFMA: sc = K·Qᵀ − m for free), no
+// rescale — and checked AFTERWARDS: a lane's partial tile sum above 2^FA_SHIFT_SPAN (or NaN) makes the wave take the classic online
+// step on the scores it still holds.  p ≤ 2^100 is a normal fp32 / bf16 number and the sums stay below 2^100 · S · max|v| < 2^127
+// for S·max|v| < 2^27.
 constexpr float FA_SHIFT_SPAN = 100.f;
 constexpr float FA_SUM_LIMIT = 1.2676506e30f;   // 2^100: a lane's partial sum of one tile (32 terms) above this => refresh the shift
 constexpr float FA_SUM_FLOOR = 7.8886091e-31f;  // 2^-100: a finished row sum below this (shift-0 sweep) => the row is redone with a true shift
-constexpr int FA_KMAX_SLOTS = 1024;   // per-tile bounds of one (batch, head) staged in LDS: S <= 65 536 (longer rows refresh every tile)
-
-AE_DEV float fa_row_norm2(const bf16x8 (&qf)[4]) {
-    float qn2 = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { const float q = (float)qf[ks][e]; qn2 += q * q; }
-    return (qn2 + __shfl_xor(qn2, 32, 64)) * FA_BOUND_SLACK;
-}
 
 AE_DEV float fa_tile_max(const f32x16 (&sc)[2]) {
     float a = fmaxf(sc[0][0], sc[1][0]), b = fmaxf(sc[0][1], sc[1][1]);
@@ -252,27 +175,25 @@ AE_DEV float fa_exp_tile(const f32x16 (&sc)[2], u32x4 (&pf)[2][2]) {
 // =================================================================================================================
 // lock-step kernel: one barrier per KV tile, double-buffered LDS (32 KiB), 2 workgroups per CU
 // =================================================================================================================
-// NW waves = NW*32 query rows per workgroup (8 or 4).  PRIO 1 = s_setprio 1 around the two MFMA clusters (a wave finishes its
-// MFMA burst instead of interleaving with the other waves' soft-max VALU, which does not overlap with it anyway): +1.5 %
-// (profiles/r01_attn_variants_v3.json; around the soft-max instead: +0.8 %).
-// ILV = 1: in a tile that passes the guard the soft-max VALU work is interleaved, inside the wave, with that wave's own MFMAs
-// (QK^T of the second 32-key half under the exponentials of the first, P·V of the first half under the exponentials of the second):
-// VALU issued between a wave's own MFMAs hides under them, VALU of the OTHER waves of the SIMD mostly does not
-// (profiles/r01_valu_probe.jsonl: 680 vs 1027 cycles for 16 MFMAs + one tile's soft-max).
-// DOT2 = row sums by v_dot2c_f32_bf16 from the rounded P pairs (fa_exp_pair).
-// QREG (ILV = 2 only) = the tile-pair loop keeps the Q fragments in 16 registers (the optimistic sweep has no shift vector to hold) instead of
-// re-reading them from LDS: 8 of the 24 ds_read_b128 per tile go away.
-template <bool WIDE_STORE, int NW, int PRIO = 1, int ILV = 0, bool DOT2 = false, bool QREG = false>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 4 : 2, 4)))   // 8 waves: <= 128 VGPRs, 16 waves per CU
+// 8 waves = 256 query rows per workgroup.  s_setprio 1 around the pure-MFMA clusters (a wave finishes its MFMA burst instead of
+// interleaving with the other waves' soft-max VALU, which does not overlap with it anyway): +1.5 % (profiles/r01_attn_variants_v3.json).
+// PAIR: the tile-pair loop (two tiles per iteration, the wave's own soft-max VALU behind 24 of its 32 MFMAs — VALU issued between a
+// wave's own MFMAs hides under them, VALU of the OTHER waves of the SIMD mostly does not: profiles/r01_valu_probe.jsonl, 680 vs 1027
+// cycles for 16 MFMAs + one tile's soft-max) with the Q fragments in 16 registers (the optimistic sweep has no shift vector to hold).
+// The generic tile takes its row sums by v_dot2c_f32_bf16 from the rounded P pairs (fa_exp_pair<true>: +4 % there — it frees the registers
+// the four add chains spill), the tile-pair loop by plain adds (dot2 measured -2 % inside it).
+template <bool WIDE_STORE, bool PAIR>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))   // <= 128 VGPRs, 16 waves per CU
 void flash_attn_fwd_kernel(FlashArgs p) {
     // 2 x (K tile + V^T tile) + this workgroup's Q fragments (4 KiB per wave, lane-linear: conflict-free ds_read_b128).  Q lives in
     // LDS, not in 16 registers per lane: the registers hold the soft-max shift vector instead (see below) and the kernel stays
     // within the 128-register budget of 4 waves per SIMD without spilling.
-    __shared__ __attribute__((aligned(16))) char smem[2 * FA_BUF + NW * 4096 + (ILV == 1 ? FA_KMAX_SLOTS * 4 : 0) + 64];
+    constexpr int NW = 8;
+    __shared__ __attribute__((aligned(16))) char smem[2 * FA_BUF + NW * 4096 + 64];
     const FaLane L = fa_lane_setup();
     const int tid = threadIdx.x, hi = L.hi;
 
-    const int wgid = xcd_remap(blockIdx.x, p.nwg) + p.wg_first;
+    const int wgid = xcd_remap(blockIdx.x, p.nwg);
     const int bh = wgid / p.nqb;
     const int qb = wgid - bh * p.nqb;
     const int S = p.S;
@@ -314,7 +235,6 @@ void flash_attn_fwd_kernel(FlashArgs p) {
     for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
     float m_run = 0.f;        // the row's current shift (log2 domain; both lanes of a row hold the same value)
     float l_run = 0.f;        // this lane's partial row sum
-    float thr2 = -1.f;        // (m_run + FA_SHIFT_SPAN)^2 when that base is positive, else -1: a tile passes iff qn2*kmax2 <= thr2
     f32x16 negm;              // -m_run in all 16 elements: the C operand of the first QK^T MFMA of every tile
 #pragma unroll
     for (int i = 0; i < 16; ++i) negm[i] = 0.f;
@@ -322,17 +242,10 @@ void flash_attn_fwd_kernel(FlashArgs p) {
     const int nkv = (S + FA_KVBLK - 1) / FA_KVBLK;
     const bool ragged = (S & (FA_KVBLK - 1)) != 0;
     stage(0, 0);
-    const float qn2 = fa_row_norm2(qf);
     char* const qs = smem + 2 * FA_BUF + L.wave * 4096 + L.lane * 16;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) *(bf16x8*)(qs + ks * 1024) = qf[ks];
-    // max||k||^2 of every KV tile of this (batch, head) -> LDS (the per-tile guard reads it with one broadcast ds_read_b32: a
-    // global load inside the loop would share vmcnt with the K/V DMA and serialise it)
-    float* const kms = (float*)(smem + 2 * FA_BUF + NW * 4096);
-    float* const votes = (float*)(smem + 2 * FA_BUF + NW * 4096 + (ILV == 1 ? FA_KMAX_SLOTS * 4 : 0));   // 8 floats of their own
-    const bool bounded = ILV == 1 && p.kmax2 != nullptr && nkv <= FA_KMAX_SLOTS;
-    if (bounded)
-        for (int i = tid; i < nkv; i += NW * 64) kms[i] = p.kmax2[(size_t)bh * (p.Spad / FA_KVBLK) + i];
+    float* const votes = (float*)(smem + 2 * FA_BUF + NW * 4096);   // 8 floats of their own
     drain_and_barrier();
 
     // Generic tile.  Tile 0 of a row refreshes (the shift becomes the tile's true maximum).  Every later tile is exponentiated
@@ -349,7 +262,7 @@ void flash_attn_fwd_kernel(FlashArgs p) {
         const char* base = smem + cur * FA_BUF;
 
         f32x16 sc[2];
-        if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const bf16x8 qv = *(const bf16x8*)(qs + ks * 1024);
@@ -359,14 +272,14 @@ void flash_attn_fwd_kernel(FlashArgs p) {
                 sc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qv, ks == 0 ? negm : sc[t], 0, 0, 0);
             }
         }
-        if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
         if (LAST && ragged) fa_mask_tail(sc, j, hi, S);
 
         u32x4 pf[2][2];
         float tsum = 0.f;
         bool redo = (j == 0);
         if (!redo) {
-            tsum = fa_exp_tile<DOT2>(sc, pf);
+            tsum = fa_exp_tile<true>(sc, pf);
             redo = __any(!(tsum <= FA_SUM_LIMIT)) != 0;
         }
         if (__builtin_expect(redo, 0)) {
@@ -381,17 +294,15 @@ void flash_attn_fwd_kernel(FlashArgs p) {
                     l_run *= alpha;
                 }
                 m_run += up;
-                const float nb = m_run + FA_SHIFT_SPAN;
-                thr2 = nb > 0.f ? nb * nb : -1.f;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { sc[0][i] -= up; sc[1][i] -= up; negm[i] = -m_run; }
             }
-            tsum = fa_exp_tile<DOT2>(sc, pf);                      // sc = s - m_run <= 0 wherever the shift moved
+            tsum = fa_exp_tile<true>(sc, pf);                      // sc = s - m_run <= 0 wherever the shift moved
         }
         l_run += tsum;
 
         // ---- O^T += V^T . P^T ----
-        if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -401,73 +312,10 @@ void flash_attn_fwd_kernel(FlashArgs p) {
                     const bf16x8 vf = *(const bf16x8*)(base + dt * 4096 + L.voff[t][s]);
                     o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pf[t][s]), o[dt], 0, 0, 0);
                 }
-        if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
         if (!LAST) drain_and_barrier();
     };
-    // ---- interleaved steady-state tile (guard already checked, not the last tile) ---------------------------------------
-    [[maybe_unused]] auto tile_ilv = [&](int j) {
-        const int cur = j & 1;
-        stage(j + 1, cur ^ 1);
-        const char* base = smem + cur * FA_BUF;
-        auto Kf = [&](int t, int ks) { return *(const bf16x8*)(base + t * 4096 + L.koff[ks]); };
-        auto Qf = [&](int ks) { return *(const bf16x8*)(qs + ks * 1024); };
-        auto Vf = [&](int dt, int t, int s2) { return *(const bf16x8*)(base + dt * 4096 + L.voff[t][s2]); };
-        f32x16 s0, s1;
-        u32x4 pf[2][2];
-        // (row sums as v_pk_fma_f32 with a register of ones — 6 cycles per two elements in isolation — measured 3 % SLOWER here than
-        // plain v_add_f32, as in round 1's lock-step kernel: profiles/r02_attn_variants.txt)
-        float ps[4] = {0.f, 0.f, 0.f, 0.f};
-        // one quarter (4 scores) of a 32-key half: exp2, row sum, bf16 P fragment elements
-        auto quarter = [&](const f32x16& sc, int t, int q) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const unsigned w = fa_exp_pair<DOT2>(sc[4 * q + 2 * e], sc[4 * q + 2 * e + 1], ps[2 * e], ps[2 * e + 1]);
-                asm volatile("" : "+v"(ps[2 * e]), "+v"(ps[2 * e + 1]));      // keep the row-sum update inside this group (IR passes re-associate and sink it otherwise)
-                pf[t][q >> 1][2 * (q & 1) + e] = w;
-            }
-        };
-        bf16x8 fa = Kf(0, 0), fq = Qf(0);
-        // segment 1: QK^T of keys 0..31 (fragments fetched one MFMA ahead)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 na = ks < 3 ? Kf(0, ks + 1) : Kf(1, 0), nq = Qf((ks + 1) & 3);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fq, ks == 0 ? negm : s0, 0, 0, 0);
-            fa = na; fq = nq;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // segment 2: QK^T of keys 32..63 || soft-max of keys 0..31
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 na = ks < 3 ? Kf(1, ks + 1) : Vf(0, 0, 0), nq = Qf((ks + 1) & 3);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fq, ks == 0 ? negm : s1, 0, 0, 0);
-            fa = na; fq = nq;
-            __builtin_amdgcn_sched_barrier(0);
-            quarter(s0, 0, ks);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // segment 3: P·V of keys 0..31 || soft-max of keys 32..63
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int s2 = g >> 1, dt = g & 1;
-            const bf16x8 na = g < 3 ? Vf((g + 1) & 1, 0, (g + 1) >> 1) : Vf(0, 1, 0);
-            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_bit_cast(bf16x8, pf[0][s2]), o[dt], 0, 0, 0);
-            fa = na;
-            __builtin_amdgcn_sched_barrier(0);
-            quarter(s1, 1, g);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // segment 4: P·V of keys 32..63
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int s2 = g >> 1, dt = g & 1;
-            const bf16x8 na = g < 3 ? Vf((g + 1) & 1, 1, (g + 1) >> 1) : fa;
-            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_bit_cast(bf16x8, pf[1][s2]), o[dt], 0, 0, 0);
-            fa = na;
-        }
-        l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
-        drain_and_barrier();
-    };
-    // ---- ILV = 2: two tiles per iteration, soft-max of each 32-key half spread over the MFMAs of its neighbours -----------------------
+    // ---- PAIR: two tiles per iteration, soft-max of each 32-key half spread over the MFMAs of its neighbours -----------------------
     // Per pair of tiles (halves h0,h1 of tile j, h2,h3 of tile j+1) the wave issues, in this order (MFMA group ∥ VALU it hides):
     //   QK h0 | QK h1 ∥ sm h0 a | QK h2 ∥ sm h0 b | PV h0 ∥ sm h1 a | QK h3 ∥ sm h1 b | PV h1 ∥ sm h2 a | X | sm h2 b | PV h2 ∥ sm h3 a | sm h3 b | PV h3 | Y
     // so 24 of the 32 MFMAs run with ~40 cycles of the wave's own soft-max VALU behind each of them (the one-tile variant pairs
@@ -489,10 +337,8 @@ void flash_attn_fwd_kernel(FlashArgs p) {
     [[maybe_unused]] auto pair_loop = [&](int npairs) {
         float ps[4] = {0.f, 0.f, 0.f, 0.f};
         bf16x8 qreg[4];
-        if (QREG) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) qreg[ks] = *(const bf16x8*)(qs + ks * 1024);
-        }
+        for (int ks = 0; ks < 4; ++ks) qreg[ks] = *(const bf16x8*)(qs + ks * 1024);
         // K(1) -> buffer 1 now, V(1) after the barrier that publishes it (K(0), V(0) were staged and published by the prologue)
         stage_k(1, 1);
         drain_and_barrier();
@@ -515,13 +361,12 @@ void flash_attn_fwd_kernel(FlashArgs p) {
             // one eighth (2 scores) of a half's soft-max
             auto eighth = [&](auto H, auto E) {
                 constexpr int h = decltype(H)::value, e = decltype(E)::value;
-                // DOT2: two alternating accumulators (ps[0], ps[2]); otherwise four add chains as before
-                const unsigned w = fa_exp_pair<DOT2>(S[h][2 * e], S[h][2 * e + 1], ps[2 * (e & 1)], ps[2 * (e & 1) + 1]);
+                const unsigned w = fa_exp_pair<false>(S[h][2 * e], S[h][2 * e + 1], ps[2 * (e & 1)], ps[2 * (e & 1) + 1]);
                 asm volatile("" : "+v"(ps[2 * (e & 1)]), "+v"(ps[2 * (e & 1) + 1]));
                 pf[h][e >> 2][e & 3] = w;
             };
             // A-operand fragments are fetched TWO MFMAs ahead (fa: this step, fb: next step, loaded now: the step after), Q fragments one
-            bf16x8 fa = afrag(ic<0>{}), fb = afrag(ic<1>{}), fq = QREG ? qreg[0] : *(const bf16x8*)(qs);
+            bf16x8 fa = afrag(ic<0>{}), fb = afrag(ic<1>{}), fq = qreg[0];
             static_for<24>([&](auto I) {                                   // steps 0..23 (up to barrier X)
                 constexpr int i = decltype(I)::value;
                 constexpr int grp = i >> 2, m = i & 3;
@@ -531,7 +376,7 @@ void flash_attn_fwd_kernel(FlashArgs p) {
                 if constexpr (i + 2 < 24) nb = afrag(ic<i + 2>{});
                 if constexpr (i + 1 < 24) {
                     constexpr int g2 = (i + 1) >> 2;
-                    if constexpr (g2 == 0 || g2 == 1 || g2 == 2 || g2 == 4) nq = QREG ? qreg[(i + 1) & 3] : *(const bf16x8*)(qs + ((i + 1) & 3) * 1024);
+                    if constexpr (g2 == 0 || g2 == 1 || g2 == 2 || g2 == 4) nq = qreg[(i + 1) & 3];
                 }
                 if constexpr (qk) S[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fq, m == 0 ? zero : S[h], 0, 0, 0);
                 else o[m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_bit_cast(bf16x8, pf[h][m >> 1]), o[m & 1], 0, 0, 0);
@@ -578,7 +423,7 @@ void flash_attn_fwd_kernel(FlashArgs p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 
-    if (ILV == 2 && nkv >= 4) {
+    if (PAIR && nkv >= 4) {
         // OPTIMISTIC sweep with shift 0 (no a-priori bound, no dependence on the weights): the tile-pair loop exponentiates the raw
         // log2-domain scores.  That is an exact soft-max (shift invariance) unless some exp2 left fp32's range — which shows in the
         // finished row: a row sum that is not finite, or so small that its terms were flushed, or a non-finite accumulator.  The
@@ -612,20 +457,6 @@ void flash_attn_fwd_kernel(FlashArgs p) {
             for (int jj = 0; jj < nkv - 1; ++jj) tile(jj, std::false_type{});
             tile(nkv - 1, std::true_type{});
         }
-    } else if (ILV == 1) {
-        // Tile 0 always refreshes.  After it, tiles that pass the a-priori guard (needs the bound table) run in the interleaved loop; the
-        // first tile that fails sends the wave to the generic loop for the rest of its sweep (exact as well, just not interleaved).
-        int j = 0;
-        if (nkv > 1) { tile(0, std::false_type{}); j = 1; }
-        float km = (bounded && j < nkv) ? kms[j] : INFINITY;          // bound of the tile about to run, fetched one tile ahead
-        for (; j < nkv - 1; ++j) {
-            if (!__all(qn2 * km <= thr2)) break;
-            km = kms[j + 1];
-            asm volatile("" : "+v"(km));                                // keep the LDS read here, a whole tile ahead of its use
-            tile_ilv(j);
-        }
-        for (; j < nkv - 1; ++j) tile(j, std::false_type{});
-        tile(nkv - 1, std::true_type{});
     } else {
         for (int j = 0; j < nkv - 1; ++j) tile(j, std::false_type{});
         tile(nkv - 1, std::true_type{});
@@ -634,490 +465,13 @@ void flash_attn_fwd_kernel(FlashArgs p) {
     fa_store<WIDE_STORE>(o, l_run, p, bh, qrow, hi);
 }
 
-// =================================================================================================================
-// software-pipelined kernel: one workgroup per CU (two waves per SIMD), soft-max of tile j interleaved, inside each
-// wave, with the MFMAs of P·V(j-1) and K(j+1)·Qᵀ
-// =================================================================================================================
-// Measured on MI355X (tools/probes/valu_probe.hip, profiles/r01_valu_probe.jsonl): VALU work issued by the SAME wave
-// between its MFMAs hides under them (16 MFMA + 32 v_exp + 32 v_add + 16 v_cvt_pk interleaved: 680 cycles against 512
-// for the bare MFMAs), whereas the same VALU work issued by the OTHER wave of the SIMD serialises with the MFMAs
-// (1027 cycles) — so the overlap has to be built inside each wave: the loop body carries two score tiles and two P
-// fragments (sc/pf of tile j being soft-maxed, sc of tile j+1 being produced, pf of tile j-1 being consumed).
-constexpr int FA_NB = 4;  // K/V ring depth (tile t lives in slot t & 3)
-
-
-// Timing ablations of this kernel (profiles/r01_attn_swp_ablation.json, shader cycles per KV tile for the two waves of
-// a SIMD): full 1721, without the LDS-DMA 1623, without the soft-max VALU 1203 (16 MFMAs = 2 x 512); fragment reads 2 / 4 /
-// 6 / 8 MFMAs ahead: 1720 / 1671 / 1703 / 1760 (profiles/r01_attn_swp_prefetch.json).
-constexpr int FA_AHEAD = 4;   // fragment reads are issued this many MFMAs ahead of their use
-
-template <bool WIDE_STORE>
-__global__ __launch_bounds__(512) void flash_attn_swp_kernel(FlashArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[FA_NB * FA_BUF];
-    const FaLane L = fa_lane_setup();
-    const int tid = threadIdx.x, hi = L.hi;
-    const int wave_s = __builtin_amdgcn_readfirstlane(L.wave);
-
-    const int wgid = xcd_remap(blockIdx.x, p.nwg);
-    const int bh = wgid / p.nqb;
-    const int qb = wgid - bh * p.nqb;
-    const int S = p.S;
-
-    const bf16_t* Qg = p.Q + (size_t)bh * S * FA_D;
-    const bf16_t* Kg = p.K + (size_t)bh * S * FA_D;
-    const bf16_t* Vg = p.Vt + (size_t)bh * FA_D * p.Spad;
-
-    const int qrow = qb * FA_QBLK + L.wave * 32 + L.l32;
-    const int qrow_c = min(qrow, S - 1);
-    bf16x8 qf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(Qg + (size_t)qrow_c * FA_D + 16 * ks + 8 * hi);
-
-    const int srow = tid >> 3;
-    const int schunk = (tid & 7) ^ ((srow >> 1) & 7);
-    char* const lds_stage = smem + wave_s * 1024;
-    const int nkv = (S + FA_KVBLK - 1) / FA_KVBLK;
-    // buffer-descriptor DMA (scalar tile advance, no per-tile VALU).  Tiles past the end re-fetch the last tile (finite
-    // data) into a slot nobody needs any more: the loop stays branch free with uniform vmcnt accounting; the scores of
-    // such a tile — like those of the keys >= S of the ragged last tile, which the K descriptor does not cover — are
-    // masked to -inf, so they contribute exactly 0.
-    const buf_rsrc_t k_rsrc = make_buf_rsrc(Kg, (unsigned)S * FA_D * 2);
-    const buf_rsrc_t v_rsrc = make_buf_rsrc(Vg, (unsigned)p.Spad * FA_D * 2);
-    const unsigned k_voff = srow * (FA_D * 2) + schunk * 16;
-    const unsigned v_voff = (unsigned)srow * p.Spad * 2 + schunk * 16;
-    auto stage_k = [&](int j, int slot) { bglds16(k_rsrc, k_voff, min(j, nkv - 1) * (FA_KVBLK * FA_D * 2), lds_stage + slot * FA_BUF); };
-    auto stage_v = [&](int j, int slot) { bglds16(v_rsrc, v_voff, min(j, nkv - 1) * (FA_KVBLK * 2), lds_stage + slot * FA_BUF + FA_TILE); };
-
-    f32x16 o[2];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
-    float m_run = -INFINITY, l_run = 0.f;
-
-    stage_k(0, 0); stage_v(0, 0); stage_k(1, 1); stage_v(1, 1); stage_k(2, 2);
-    const bool fast = fa_fast_ok(qf, p.kmax2, bh, p.Spad / FA_KVBLK);
-    drain_and_barrier();
-
-    auto sweep = [&](auto fast_tag) {
-        constexpr bool FAST = decltype(fast_tag)::value;
-        f32x16 sc_a[2], sc_b[2];
-        u32x4 pf_a[2][2], pf_b[2][2];   // P fragments as packed bf16 pairs
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) pf_b[t][s][e] = 0u;
-        // prologue: scores of tile 0
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sc_a[t][i] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                sc_a[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(smem + t * 4096 + L.koff[ks]), qf[ks], sc_a[t], 0, 0, 0);
-        }
-        f32x2 lsum[2] = {{0.f, 0.f}, {0.f, 0.f}};   // FAST: packed partial row sums (v_pk_fma_f32 with 1.0)
-        f32x2 ones = {1.f, 1.f};
-        asm volatile("" : "+v"(ones));   // opaque: keeps v_pk_fma_f32 (6 cycles / wave) from being folded to v_pk_add_f32 (11.6)
-
-        // One iteration = tile j (ring slots are compile-time: the loop is unrolled by 4):
-        //   MFMA  o += Vᵀ(j-1)·pf_prev (8) then sc_nxt = K(j+1)·Qᵀ (8);   VALU  pf_cur = softmax(sc_cur)
-        // LDS ring at iteration j: Vᵀ(j-1), [Vᵀ(j)], K(j+1) are read/live; K(j+3) -> K half of slot (j-1)&3 (last read at
-        // iteration j-2) and Vᵀ(j+2) -> V half of slot (j-2)&3 (last read at iteration j-1) are issued now and waited for
-        // one iteration later (vmcnt(2)): K lands two iterations ahead of its use, Vᵀ three.
-        auto iter = [&](int j, auto slot_tag, f32x16 (&sc_cur)[2], f32x16 (&sc_nxt)[2], u32x4 (&pf_prev)[2][2], u32x4 (&pf_cur)[2][2]) {
-            constexpr int SL = decltype(slot_tag)::value;          // j & 3
-            constexpr int KSLOT = (SL + 1) & 3, VSLOT = (SL + 3) & 3;   // slots of tile j+1 and tile j-1
-            if constexpr (!FAST) {
-                stage_k(j + 3, VSLOT);                              // (j+3)&3 == (j-1)&3
-                stage_v(j + 2, (SL + 2) & 3);
-            }
-            if ((j + 1) * FA_KVBLK > S) fa_mask_tail(sc_cur, j, hi, S);
-            // j = 0: pf_prev is 0 and slot 3 is still uninitialised LDS (0 x NaN): read tile 0's Vᵀ instead
-            const char* kbase = smem + KSLOT * FA_BUF;
-            const char* vbase = smem + ((SL == 0 && j == 0) ? 0 : VSLOT) * FA_BUF;
-            // fragment i of the 16 MFMAs: 0-7 Vᵀ(dt = i&1, t = i>>2, s = (i>>1)&1), 8-15 K(t = i&1, ks = (i-8)>>1)
-            auto frag = [&](auto I) -> bf16x8 {
-                constexpr int i = decltype(I)::value;
-                if constexpr (i < 8) return *(const bf16x8*)(vbase + (i & 1) * 4096 + L.voff[i >> 2][(i >> 1) & 1]);
-                else return *(const bf16x8*)(kbase + (i & 1) * 4096 + L.koff[(i - 8) >> 1]);
-            };
-            if constexpr (FAST) {
-                // hand interleave, pinned by sched_barrier: per MFMA one fragment read (two ahead) and the soft-max of two
-                // scores (2 v_exp, 1 v_pk_fma row sum, 1 v_cvt_pk)
-                bf16x8 fr[16];
-                static_for<FA_AHEAD>([&](auto I) { fr[decltype(I)::value] = frag(I); });
-                static_for<16>([&](auto I) {
-                    constexpr int i = decltype(I)::value;
-                    if constexpr (i + FA_AHEAD < 16) fr[i + FA_AHEAD] = frag(ic<i + FA_AHEAD>{});
-                    // the two DMA pieces of this iteration go out in the shadow of the MFMAs, not at the barrier
-                    if constexpr (i == 2) stage_k(j + 3, VSLOT);            // (j+3)&3 == (j-1)&3
-                    if constexpr (i == 9) stage_v(j + 2, (SL + 2) & 3);
-                    if constexpr (i < 8) {
-                        o[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], __builtin_bit_cast(bf16x8, pf_prev[i >> 2][(i >> 1) & 1]), o[i & 1], 0, 0, 0);
-                    } else {
-                        constexpr int t = i & 1, ks = (i - 8) >> 1;
-                        if constexpr (ks == 0) {
-                            f32x16 z;
-#pragma unroll
-                            for (int e = 0; e < 16; ++e) z[e] = 0.f;
-                            sc_nxt[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], qf[ks], z, 0, 0, 0);
-                        } else {
-                            sc_nxt[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], qf[ks], sc_nxt[t], 0, 0, 0);
-                        }
-                    }
-                    // scores 2i, 2i+1 of this lane: tile t = i>>3, slab s = (i>>2)&1, elements e = 2(i&3), +1
-                    constexpr int t = i >> 3, s = (i >> 2) & 1, e = 2 * (i & 3);
-                    f32x2 pp;
-                    pp[0] = __builtin_amdgcn_exp2f(sc_cur[t][8 * s + e]);
-                    pp[1] = __builtin_amdgcn_exp2f(sc_cur[t][8 * s + e + 1]);
-                    lsum[i & 1] = __builtin_elementwise_fma(pp, ones, lsum[i & 1]);
-                    unsigned w = pack_bf16x2(pp[0], pp[1]);
-                    // the results are first USED one iteration later: without these anchors the compiler sinks the whole
-                    // soft-max past the barrier, next to its use, and the interleave is gone
-                    asm volatile("" : "+v"(w), "+v"(lsum[i & 1]));
-                    pf_cur[t][s][e / 2] = w;
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-            } else {
-                // exact online soft-max: compiler-scheduled (the MFMAs below do not depend on this tile's soft-max)
-                static_for<16>([&](auto I) {
-                    constexpr int i = decltype(I)::value;
-                    const bf16x8 f = frag(I);
-                    if constexpr (i < 8) {
-                        o[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, __builtin_bit_cast(bf16x8, pf_prev[i >> 2][(i >> 1) & 1]), o[i & 1], 0, 0, 0);
-                    } else {
-                        constexpr int t = i & 1, ks = (i - 8) >> 1;
-                        if constexpr (ks == 0) {
-#pragma unroll
-                            for (int e = 0; e < 16; ++e) sc_nxt[t][e] = 0.f;
-                        }
-                        sc_nxt[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, qf[ks], sc_nxt[t], 0, 0, 0);
-                    }
-                });
-                bf16x8 pfx[2][2];
-                fa_softmax<false>(sc_cur, pfx, o, m_run, l_run);
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        pf_cur[t][s] = __builtin_bit_cast(u32x4, pfx[t][s]);
-                        asm volatile("" : "+v"(pf_cur[t][s]));   // keep the soft-max in this iteration (see above)
-                    }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            block_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        };
-
-        const int n4 = (nkv + 3) & ~3;   // the tile count is padded to a multiple of 4 with fully masked tiles
-        for (int j = 0; j < n4; j += 4) {
-            iter(j, ic<0>{}, sc_a, sc_b, pf_b, pf_a);
-            iter(j + 1, ic<1>{}, sc_b, sc_a, pf_a, pf_b);
-            iter(j + 2, ic<2>{}, sc_a, sc_b, pf_b, pf_a);
-            iter(j + 3, ic<3>{}, sc_b, sc_a, pf_a, pf_b);
-        }
-        // epilogue: P·V of the last tile (pf_b), Vᵀ(n4-1) lives in slot 3
-        {
-            const char* vbase = smem + 3 * FA_BUF;
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt)
-                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(vbase + dt * 4096 + L.voff[t][s]), __builtin_bit_cast(bf16x8, pf_b[t][s]), o[dt], 0, 0, 0);
-        }
-        if constexpr (FAST) l_run += (lsum[0][0] + lsum[0][1]) + (lsum[1][0] + lsum[1][1]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant tail DMA must not outlive the workgroup's LDS
-    };
-    if (fast) sweep(std::true_type{});
-    else sweep(std::false_type{});
-
-    fa_store<WIDE_STORE>(o, l_run, p, bh, qrow, hi);
-}
-
-
-// =================================================================================================================
-// 64-rows-per-wave kernel (AETHER_ATTN_ROWS64): every K / V fragment read from LDS feeds TWO MFMAs
-// =================================================================================================================
-// What limits the 32-row kernels above is not the matrix pipe (57-66 % busy) but the wave's own issue stream: per KV tile a wave issues,
-// besides 16 MFMAs and ~80 soft-max VALU, 16-24 ds_read_b128, two LDS-DMA pieces, waits and a barrier (keeping the Q fragments in
-// registers — 8 reads fewer per tile — measured +4 %, profiles/r03_attn_variants.txt).  Here a wave owns 64 query rows (two 32-row blocks):
-// the K fragment of a k-step multiplies both blocks' Q fragments and the V fragment both blocks' P fragments, so K/V fragment reads per
-// MFMA drop from 1 to 0.5, Q lives in registers (0 reads), and a workgroup of 4 waves (256 rows, as before) stages the same 16 KiB per
-// KV tile with half the DMA instructions per MFMA.  256 registers per lane -> two waves per SIMD (two workgroups per CU).
-//
-// Schedule (software pipeline over 32-key halves; scA / scB = scores of an even / odd half, pfA / pfB its P fragments); iteration j:
-//   slot 1   QK(tile j, keys 32-63) -> scB      ∥ soft-max of scA, block 0 -> pfA[0]
-//   slot 2   PV(tile j-1, keys 32-63) with pfB  ∥ soft-max of scA, block 1 -> pfA[1]
-//   slot 3   QK(tile j+1, keys 0-31) -> scA     ∥ soft-max of scB, block 0 -> pfB[0]
-//   slot 4   PV(tile j, keys 0-31) with pfA     ∥ soft-max of scB, block 1 -> pfB[1]
-//   s_waitcnt vmcnt(0); s_barrier;  LDS-DMA of K(j+3) and V(j+2) into the ring slots K(j) and V(j-1) just left
-// Every slot is 8 MFMAs (4 fragments, each used twice) with the soft-max of two scores of the wave's own rows behind each MFMA.
-// K and V live in separate rings of three 8 KiB slots (48 KiB per workgroup): a tile's DMA has a whole iteration to land.
-// Soft-max: the optimistic shift-0 sweep of the tile-pair kernel (exact by shift invariance unless an exp2 left fp32's range, which the
-// finished rows show; the workgroup then votes and redoes its sweep with the classic online soft-max, `rows64_conservative`).
-// NW = 4: 256-row workgroups, two per CU;  NW = 8 (AETHER_ATTN_WG512): 512-row workgroups, one per CU — every staged KV tile then serves twice
-// the MFMAs, i.e. half the LDS-DMA instructions per MFMA (an LDS-DMA piece costs its issuing wave 60-185 cycles).
-template <bool WIDE_STORE, bool DOT2, int NW>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void flash_attn_rows64_kernel(FlashArgs p) {
-    constexpr int RING = 3;
-    constexpr int PASSES = 8 / NW;
-    __shared__ __attribute__((aligned(16))) char smem[2 * RING * FA_TILE + 64];
-    char* const kring = smem;
-    char* const vring = smem + RING * FA_TILE;
-    float* const votes = (float*)(smem + 2 * RING * FA_TILE);
-    const FaLane L = fa_lane_setup();
-    const int tid = threadIdx.x, hi = L.hi;
-    int voff[2][2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) voff[t][s2] = L.voff[t][s2] - FA_TILE;      // relative to the V tile
-
-    const int wgid = xcd_remap(blockIdx.x, p.nwg);
-    const int bh = wgid / p.nqb;
-    const int qb = wgid - bh * p.nqb;
-    const int S = p.S;
-    const bf16_t* Qg = p.Q + (size_t)bh * S * FA_D;
-    const bf16_t* Kg = p.K + (size_t)bh * S * FA_D;
-    const bf16_t* Vg = p.Vt + (size_t)bh * FA_D * p.Spad;
-
-    // ---- Q fragments of both 32-row blocks, in registers for the whole sweep --------------------------------------------------------------
-    int qrow[2];
-    bf16x8 qf[2][4];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        qrow[b] = qb * (NW * 64) + L.wave * 64 + b * 32 + L.l32;
-        const int qc = min(qrow[b], S - 1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[b][ks] = *(const bf16x8*)(Qg + (size_t)qc * FA_D + 16 * ks + 8 * hi);
-    }
-
-    // ---- staging: 512 16-byte pieces of K and of V^T per tile, two of each per thread ------------------------------------------------------
-    const int srow = tid >> 3;
-    const int schunk = (tid & 7) ^ ((srow >> 1) & 7);
-    const int wave_s = __builtin_amdgcn_readfirstlane(L.wave);
-    const buf_rsrc_t k_rsrc = make_buf_rsrc(Kg, (unsigned)S * FA_D * 2);
-    const buf_rsrc_t v_rsrc = make_buf_rsrc(Vg, (unsigned)p.Spad * FA_D * 2);
-    const unsigned k_voff = srow * (FA_D * 2) + schunk * 16;
-    const unsigned v_voff = (unsigned)srow * p.Spad * 2 + schunk * 16;
-    auto stage_k = [&](int j, int slot) {
-#pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps)
-            bglds16(k_rsrc, k_voff + ps * (NW * 8) * (FA_D * 2), j * (FA_KVBLK * FA_D * 2), kring + slot * FA_TILE + wave_s * 1024 + ps * (NW * 1024));
-    };
-    auto stage_v = [&](int j, int slot) {
-#pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps)
-            bglds16(v_rsrc, v_voff + ps * (NW * 8) * (unsigned)p.Spad * 2, j * (FA_KVBLK * 2), vring + slot * FA_TILE + wave_s * 1024 + ps * (NW * 1024));
-    };
-
-    const int nkv = (S + FA_KVBLK - 1) / FA_KVBLK;
-    const bool ragged = (S & (FA_KVBLK - 1)) != 0;
-    f32x16 o[2][2];
-    float l_run[2];
-    auto reset_acc = [&]() {
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            l_run[b] = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { o[b][0][i] = 0.f; o[b][1][i] = 0.f; }
-        }
-    };
-    // scores of half t of tile j: sc[r] = score(q = l32, key = 64j + 32t + 16(r>>3) + 8hi + (r&7)); keys >= S -> -inf
-    auto mask_half = [&](f32x16 (&sc)[2], int j, int t) {
-        const int kb = j * FA_KVBLK + 32 * t + 8 * hi;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (kb + 16 * (r >> 3) + (r & 7) >= S) { sc[0][r] = -INFINITY; sc[1][r] = -INFINITY; }
-    };
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-
-    // =========================================== optimistic sweep (shift 0) ==================================================================
-    bool need_redo = true;
-    if (nkv >= 3) {
-        reset_acc();
-        stage_k(0, 0); stage_k(1, 1); stage_k(2, 2); stage_v(0, 0); stage_v(1, 1);
-        drain_and_barrier();
-        f32x16 scA[2], scB[2];
-        u32x4 pfA[2][2], pfB[2][2];
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) pfB[b][s2][e] = 0u;
-        // prologue: scores of tile 0, keys 0..31
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 kf = *(const bf16x8*)(kring + L.koff[ks]);
-            scA[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][ks], ks == 0 ? zero : scA[0], 0, 0, 0);
-            scA[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][ks], ks == 0 ? zero : scA[1], 0, 0, 0);
-        }
-        float ps[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-        // soft-max of two scores (elements 2e, 2e+1) of block b of a half: exp2, packed bf16 pair, row-sum update
-        auto sm2 = [&](const f32x16& sc, u32x4 (&pf)[2], int b, int e) {
-            const unsigned w = fa_exp_pair<DOT2>(sc[2 * e], sc[2 * e + 1], ps[b][0], ps[b][1]);
-            asm volatile("" : "+v"(ps[b][0]), "+v"(ps[b][1]));
-            pf[e >> 2][e & 3] = w;
-        };
-        // slot = 8 MFMAs from 4 fragments (each feeds both query blocks) + the soft-max of 16 scores of block `smb` of `sc_sm`
-        auto qk_slot = [&](const char* kbase, f32x16 (&sc_out)[2], const f32x16 (&sc_sm)[2], u32x4 (&pf_sm)[2][2], auto SMB) {
-            constexpr int smb = decltype(SMB)::value;
-            bf16x8 kf = *(const bf16x8*)(kbase + L.koff[0]);
-            static_for<4>([&](auto KS) {
-                constexpr int ks = decltype(KS)::value;
-                bf16x8 nf = kf;
-                if constexpr (ks < 3) nf = *(const bf16x8*)(kbase + L.koff[ks + 1]);
-                sc_out[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][ks], ks == 0 ? zero : sc_out[0], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                sm2(sc_sm[smb], pf_sm[smb], smb, 2 * ks);
-                __builtin_amdgcn_sched_barrier(0);
-                sc_out[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][ks], ks == 0 ? zero : sc_out[1], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                sm2(sc_sm[smb], pf_sm[smb], smb, 2 * ks + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                kf = nf;
-            });
-        };
-        auto pv_slot = [&](const char* vbase, int t, const u32x4 (&pf_in)[2][2], const f32x16 (&sc_sm)[2], u32x4 (&pf_sm)[2][2], auto SMB) {
-            constexpr int smb = decltype(SMB)::value;
-            bf16x8 vf = *(const bf16x8*)(vbase + voff[t][0]);
-            static_for<4>([&](auto G) {
-                constexpr int g = decltype(G)::value;          // fragment g: s2 = g >> 1, dt = g & 1
-                constexpr int s2 = g >> 1, dt = g & 1;
-                bf16x8 nf = vf;
-                if constexpr (g < 3) nf = *(const bf16x8*)(vbase + ((g + 1) & 1) * 4096 + voff[t][(g + 1) >> 1]);
-                o[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pf_in[0][s2]), o[0][dt], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                sm2(sc_sm[smb], pf_sm[smb], smb, 2 * g);
-                __builtin_amdgcn_sched_barrier(0);
-                o[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pf_in[1][s2]), o[1][dt], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                sm2(sc_sm[smb], pf_sm[smb], smb, 2 * g + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                vf = nf;
-            });
-        };
-        int sk = 0;                                            // ring slot of K(j) = V(j); K(j+1): sk1; V(j-1), K(j+2): sk2
-        for (int j = 0; j < nkv; ++j) {
-            const int sk1 = sk == 2 ? 0 : sk + 1, sk2 = sk == 0 ? 2 : sk - 1;
-            const bool last = j == nkv - 1;
-            if (last && ragged) mask_half(scA, j, 0);
-            qk_slot(kring + sk * FA_TILE + 4096, scB, scA, pfA, ic<0>{});                                   // slot 1
-            pv_slot(vring + (j == 0 ? sk : sk2) * FA_TILE, 1, pfB, scA, pfA, ic<1>{});                    // slot 2 (j = 0: pfB = 0, any finite V)
-            if (last && ragged) mask_half(scB, j, 1);
-            qk_slot(kring + sk1 * FA_TILE, scA, scB, pfB, ic<0>{});                                         // slot 3 (past the end: unused scores)
-            pv_slot(vring + sk * FA_TILE, 0, pfA, scB, pfB, ic<1>{});                                       // slot 4
-            drain_and_barrier();
-            if (j + 3 < nkv) stage_k(j + 3, sk);
-            if (j + 2 < nkv) stage_v(j + 2, sk2);
-            sk = sk1;
-        }
-        // epilogue: P·V of the last half (keys 32..63 of tile nkv-1; its V sits in the slot before `sk`)
-        {
-            const char* vbase = vring + (sk == 0 ? 2 : sk - 1) * FA_TILE;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int s2 = g >> 1, dt = g & 1;
-                const bf16x8 vf = *(const bf16x8*)(vbase + dt * 4096 + voff[1][s2]);
-                o[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pfB[0][s2]), o[0][dt], 0, 0, 0);
-                o[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pfB[1][s2]), o[1][dt], 0, 0, 0);
-            }
-        }
-        l_run[0] = ps[0][0] + ps[0][1];
-        l_run[1] = ps[1][0] + ps[1][1];
-        // validity of the finished rows (see the tile-pair kernel): finite sums not below 2^-100, finite accumulators
-        bool ok = true;
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const float l_tot = l_run[b] + __shfl_xor(l_run[b], 32, 64);
-            float chk = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { chk = fmaf(o[b][0][i], 0.f, chk); chk = fmaf(o[b][1][i], 0.f, chk); }
-            ok = ok && (l_tot >= FA_SUM_FLOOR && l_tot < INFINITY && chk == 0.f);
-        }
-        const bool mine = __all(ok) != 0;
-        block_barrier();
-        if (L.lane == 0) votes[L.wave] = mine ? 1.f : 0.f;
-        block_barrier();
-        bool all_ok = true;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) all_ok = all_ok && (votes[w] != 0.f);
-        need_redo = !all_ok;
-    }
-
-    // =========================================== conservative sweep (classic online soft-max) ==============================================
-    if (need_redo) {
-        reset_acc();
-        float m_run[2] = {-INFINITY, -INFINITY};
-        block_barrier();
-        stage_k(0, 0); stage_v(0, 0);
-        drain_and_barrier();
-        for (int j = 0; j < nkv; ++j) {
-            const int cur = j & 1;
-            if (j + 1 < nkv) { stage_k(j + 1, cur ^ 1); stage_v(j + 1, cur ^ 1); }
-            const char* kbase = kring + cur * FA_TILE;
-            const char* vbase = vring + cur * FA_TILE;
-            f32x16 sc[2][2];                                  // [half t][block b]
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const bf16x8 kf = *(const bf16x8*)(kbase + t * 4096 + L.koff[ks]);
-                    sc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][ks], ks == 0 ? zero : sc[t][0], 0, 0, 0);
-                    sc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][ks], ks == 0 ? zero : sc[t][1], 0, 0, 0);
-                }
-            if (j == nkv - 1 && ragged) { mask_half(sc[0], j, 0); mask_half(sc[1], j, 1); }
-            u32x4 pf[2][2][2];                                // [half t][block b][slab s2]
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                float mx = sc[0][b][0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[0][b][r]);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[1][b][r]);
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                const float m_new = fmaxf(m_run[b], mx);      // finite from tile 0 on: every tile holds at least one unmasked key
-                const float alpha = __builtin_amdgcn_exp2f(m_run[b] - m_new);   // 0 on the first tile
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { o[b][0][i] *= alpha; o[b][1][i] *= alpha; }
-                l_run[b] *= alpha;
-                m_run[b] = m_new;
-                float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        pf[t][b][e >> 2][e & 3] = fa_exp_pair<DOT2>(sc[t][b][2 * e] - m_new, sc[t][b][2 * e + 1] - m_new, s0, s1);
-                l_run[b] += s0 + s1;
-            }
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int s2 = g >> 1, dt = g & 1;
-                    const bf16x8 vf = *(const bf16x8*)(vbase + dt * 4096 + voff[t][s2]);
-                    o[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pf[t][0][s2]), o[0][dt], 0, 0, 0);
-                    o[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pf[t][1][s2]), o[1][dt], 0, 0, 0);
-                }
-            drain_and_barrier();
-        }
-    }
-    fa_store<WIDE_STORE>(o[0], l_run[0], p, bh, qrow[0], hi);
-    fa_store<WIDE_STORE>(o[1], l_run[1], p, bh, qrow[1], hi);
-}
 
 }  // namespace aether
 
 using namespace aether;
 
 extern "C" int aether_flash_attn_fwd(const void* Qh, const void* Kh, const void* Vt, void* O, int B, int H, int S,
-                                     int Spad, const float* kmax2, int flags, void* stream) {
+                                     int Spad, int flags, void* stream) {
     if (!Qh || !Kh || !Vt || !O) return aether_set_error(AETHER_ERR_ARG, "flash_attn: null pointer");
     if (B <= 0 || H <= 0 || S <= 0) return aether_set_error(AETHER_ERR_SHAPE, "flash_attn: empty problem");
     if (Spad % FA_KVBLK != 0 || Spad < S) return aether_set_error(AETHER_ERR_SHAPE, "flash_attn: Spad must be roundup(S,64)");
@@ -1125,61 +479,16 @@ extern "C" int aether_flash_attn_fwd(const void* Qh, const void* Kh, const void*
         return aether_set_error(AETHER_ERR_ALIGN, "flash_attn: pointers must be 16-byte aligned");
     FlashArgs p;
     p.Q = (const bf16_t*)Qh; p.K = (const bf16_t*)Kh; p.Vt = (const bf16_t*)Vt; p.O = (bf16_t*)O;
-    p.kmax2 = (flags & AETHER_ATTN_EXACT_MAX) ? nullptr : kmax2;
     p.H = H; p.S = S; p.Spad = Spad;
     p.nqb = (S + FA_QBLK - 1) / FA_QBLK;
     p.nwg = p.nqb * B * H;
-    p.wg_first = 0;
     hipStream_t s = (hipStream_t)stream;
-    const bool wide = (flags & AETHER_GEMM_WIDE_STORE) != 0;
-    dim3 grid(p.nwg), block(512);
-    if ((flags & AETHER_ATTN_ROWS64) && !(flags & (AETHER_ATTN_PIPELINED | AETHER_ATTN_EXACT_MAX))) {
-        const bool dot2 = (flags & AETHER_ATTN_DOT2_SUM) != 0;
-        if (flags & AETHER_ATTN_WG512) {
-            p.nqb = (S + 511) / 512;
-            p.nwg = p.nqb * B * H;
-            const dim3 g2(p.nwg), b2(512);
-            if (wide && dot2) hipLaunchKernelGGL((flash_attn_rows64_kernel<true, true, 8>), g2, b2, 0, s, p);
-            else if (wide) hipLaunchKernelGGL((flash_attn_rows64_kernel<true, false, 8>), g2, b2, 0, s, p);
-            else if (dot2) hipLaunchKernelGGL((flash_attn_rows64_kernel<false, true, 8>), g2, b2, 0, s, p);
-            else hipLaunchKernelGGL((flash_attn_rows64_kernel<false, false, 8>), g2, b2, 0, s, p);
-        } else if (wide && dot2) hipLaunchKernelGGL((flash_attn_rows64_kernel<true, true, 4>), grid, dim3(256), 0, s, p);
-        else if (wide) hipLaunchKernelGGL((flash_attn_rows64_kernel<true, false, 4>), grid, dim3(256), 0, s, p);
-        else if (dot2) hipLaunchKernelGGL((flash_attn_rows64_kernel<false, true, 4>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((flash_attn_rows64_kernel<false, false, 4>), grid, dim3(256), 0, s, p);
-    } else if (flags & AETHER_ATTN_PIPELINED) {
-        if (wide) hipLaunchKernelGGL((flash_attn_swp_kernel<true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((flash_attn_swp_kernel<false>), grid, block, 0, s, p);
-    } else {
-        // lock-step kernel: 512 resident workgroup slots (2 x 8 waves per CU at 128 VGPRs).  With AETHER_ATTN_TAIL_SPLIT whole
-        // rounds run as 256-row workgroups and the remainder as twice as many 128-row workgroups (4 per CU); measured gain
-        // <= 1 % (profiles/r01_attn_variants_v2.json), so the default is ONE launch of 256-row workgroups.
-        const int slots = 512;
-        const int full = (flags & AETHER_ATTN_TAIL_SPLIT) ? p.nwg / slots * slots : p.nwg;
-        const int rest = p.nwg - full;
-        if (full > 0) {
-            p.nwg = full; p.wg_first = 0;
-            const int ilv = (flags & AETHER_ATTN_EXACT_MAX) ? 0 : (flags & AETHER_ATTN_PAIR_PIPELINE) ? 2 : (flags & AETHER_ATTN_INTERLEAVE) ? 1 : 0;
-            // row sums by v_dot2c: slower inside the tile-pair loop (-2 %), faster in the generic tile (+4 %: it also frees the registers the
-            // four add chains spill) — so the conservative path, whose hot loop IS the generic tile, always takes it
-            const bool dot2 = (flags & AETHER_ATTN_DOT2_SUM) != 0 || (ilv == 0 && (flags & AETHER_ATTN_EXACT_MAX) != 0);
-            const bool qreg = (flags & AETHER_ATTN_QREG) != 0 && ilv == 2;
-            auto launch = [&](auto W, auto I, auto D) {
-                constexpr int ILV_ = decltype(I)::value;
-                if constexpr (ILV_ == 2) {
-                    if (qreg) { hipLaunchKernelGGL((flash_attn_fwd_kernel<decltype(W)::value, 8, 1, 2, decltype(D)::value, true>), dim3(full), dim3(512), 0, s, p); return; }
-                }
-                hipLaunchKernelGGL((flash_attn_fwd_kernel<decltype(W)::value, 8, 1, ILV_, decltype(D)::value>), dim3(full), dim3(512), 0, s, p);
-            };
-            auto by_dot2 = [&](auto W, auto I) { if (dot2) launch(W, I, std::true_type{}); else launch(W, I, std::false_type{}); };
-            auto by_ilv = [&](auto W) { if (ilv == 2) by_dot2(W, ic<2>{}); else if (ilv == 1) by_dot2(W, ic<1>{}); else by_dot2(W, ic<0>{}); };
-            if (wide) by_ilv(std::true_type{}); else by_ilv(std::false_type{});
-        }
-        if (rest > 0) {
-            p.nqb *= 2; p.nwg = 2 * rest; p.wg_first = 2 * full;
-            if (wide) hipLaunchKernelGGL((flash_attn_fwd_kernel<true, 4>), dim3(2 * rest), dim3(256), 0, s, p);
-            else hipLaunchKernelGGL((flash_attn_fwd_kernel<false, 4>), dim3(2 * rest), dim3(256), 0, s, p);
-        }
-    }
+    const bool wide = (flags & AETHER_GEMM_WIDE_STORE) != 0, pair = !(flags & AETHER_ATTN_EXACT_MAX);
+    // ONE launch of 256-row workgroups (512 resident slots: 2 x 8 waves per CU at 128 VGPRs)
+    const dim3 grid(p.nwg), block(512);
+    if (wide && pair) hipLaunchKernelGGL((flash_attn_fwd_kernel<true, true>), grid, block, 0, s, p);
+    else if (wide) hipLaunchKernelGGL((flash_attn_fwd_kernel<true, false>), grid, block, 0, s, p);
+    else if (pair) hipLaunchKernelGGL((flash_attn_fwd_kernel<false, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((flash_attn_fwd_kernel<false, false>), grid, block, 0, s, p);
     return aether_check_launch("flash_attn_fwd");
 }

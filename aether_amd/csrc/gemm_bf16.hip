@@ -4,8 +4,7 @@
 // transformer call (aether/pipelines/aetherv1_pipeline_cogvideox.py:865-875): to_q/to_k/to_v, to_out,
 // ff.net.0.proj (+GELU-tanh), ff.net.2 (+gate·x+residual), patch_embed.proj/text_proj, proj_out.
 // Kernel: gemm_kernel.hpp, 256x256x64 tile (2x4 waves, 128x64 per wave).
-#include "gemm4_kernel.hpp"
-#include "gemm_persist_kernel.hpp"
+#include "gemm_kernel.hpp"
 #include "../../include/aether_hip.h"
 
 using namespace aether;
@@ -96,7 +95,6 @@ extern "C" int aether_gemm_bf16(const void* A, int lda, const void* W, int ldw, 
     p.n_text = n_text;
     p.tiles_m = (M + 255) / 256;
     p.tiles_n = (N + 255) / 256;
-    p.stagger = (flags >> 2) & 3;
     p.a_bytes = (unsigned)(((size_t)(M - 1) * lda + K) * 2);
     p.w_bytes = (unsigned)(((size_t)(N - 1) * ldw + K) * 2);
     dim3 block(512);
@@ -111,40 +109,15 @@ extern "C" int aether_gemm_bf16(const void* A, int lda, const void* W, int ldw, 
     if (ks > nk / 4) ks = nk / 4;
     // (a launch of fewer than 256 tiles splits too when it would leave most CUs idle for a whole tile time and K is long enough to share:
     // the 108-tile remainder of the fused qkv projection, aether_dit_forward)
-    const bool lone_tail = full == 0 && rest >= 64 && nk >= 32;
+    const bool lone_tail = (flags & AETHER_GEMM_SPLIT_LONE_TAIL) != 0 && full == 0 && rest >= 64 && nk >= 32;
     if (ks < 2 || splitk_ws == nullptr || (full == 0 && !lone_tail) || (((uintptr_t)splitk_ws) & 15) ||
         (size_t)ks * rest * 256 * 256 * sizeof(float) > splitk_ws_bytes)
         ks = 1;
-    const bool four_wave = (flags & AETHER_GEMM_4WAVE) != 0;
-    const bool persistent = (flags & AETHER_GEMM_PERSISTENT) && p.stagger == 1 && !four_wave && tiles > NCU;
-    if (persistent) {
-        // persistent grid (gemm_persist_kernel.hpp).  Short last round (split-K tail available): 256 workgroups stream the FULL rounds,
-        // the tail launch below takes the rest.  Otherwise G = ceil(tiles / rounds) workgroups own whole tiles and there is no tail.
-        p.ntile_launch = (ks > 1) ? full : tiles; p.ksplit = 1;
-        const int rounds = (p.ntile_launch + NCU - 1) / NCU;
-        const int G = 8 * (((p.ntile_launch + 7) / 8 + rounds - 1) / rounds);       // per XCD: ceil(band / rounds) workgroups; <= 256
-#define LAUNCH_P(E)                                                                                                       \
-        do {                                                                                                              \
-            if (wide) hipLaunchKernelGGL((gemm_bf16_persistent_kernel<E, true>), dim3(G), block, 0, s, p);                 \
-            else hipLaunchKernelGGL((gemm_bf16_persistent_kernel<E, false>), dim3(G), block, 0, s, p);                     \
-        } while (0)
-        switch (epilogue) {
-            case EPI_BIAS: LAUNCH_P(EPI_BIAS); break;
-            case EPI_BIAS_GELU: LAUNCH_P(EPI_BIAS_GELU); break;
-            default: LAUNCH_P(EPI_BIAS_GATE_RES); break;
-        }
-#undef LAUNCH_P
-        rc = aether_check_launch("gemm_bf16 (persistent)");
-        if (rc || ks == 1) return rc;
-    }
     p.ntile_launch = (ks > 1) ? full : tiles;
 #define LAUNCH(E)                                                                                                        \
     do {                                                                                                                 \
         dim3 grid(p.ntile_launch * p.ksplit);                                                                            \
-        if (four_wave && p.ksplit == 1) {                                                                                \
-            if (wide) hipLaunchKernelGGL((gemm4_bf16_kernel<E, true>), grid, dim3(256), 0, s, p);                         \
-            else hipLaunchKernelGGL((gemm4_bf16_kernel<E, false>), grid, dim3(256), 0, s, p);                             \
-        } else if (wide) hipLaunchKernelGGL((gemm_bf16_kernel<2, 4, 4, 2, E, true, false>), grid, block, 0, s, p);        \
+        if (wide) hipLaunchKernelGGL((gemm_bf16_kernel<2, 4, 4, 2, E, true, false>), grid, block, 0, s, p);               \
         else hipLaunchKernelGGL((gemm_bf16_kernel<2, 4, 4, 2, E, false, false>), grid, block, 0, s, p);                   \
     } while (0)
 #define LAUNCH_EPI()                                        \
@@ -153,7 +126,7 @@ extern "C" int aether_gemm_bf16(const void* A, int lda, const void* W, int ldw, 
         case EPI_BIAS_GELU: LAUNCH(EPI_BIAS_GELU); break;   \
         default: LAUNCH(EPI_BIAS_GATE_RES); break;          \
     }
-    if (!persistent && !(ks > 1 && full == 0)) {
+    if (!(ks > 1 && full == 0)) {
         p.ksplit = 1;
         LAUNCH_EPI();
         rc = aether_check_launch("gemm_bf16");
@@ -199,7 +172,6 @@ extern "C" int aether_gemm_qkv_prep(const void* A, int lda, const void* W, int l
     p.M = M; p.N = N; p.K = K; p.bias = bias;
     p.rows_per_batch = S; p.n_text = n_text;
     p.tiles_m = (M + 255) / 256; p.tiles_n = N / 256;
-    p.stagger = (flags >> 2) & 3;
     p.a_bytes = (unsigned)(((size_t)(M - 1) * lda + K) * 2);
     p.w_bytes = (unsigned)(((size_t)(N - 1) * ldw + K) * 2);
     p.ksplit = 1; p.tile_base = 0; p.ntile_launch = p.tiles_m * p.tiles_n;

@@ -41,8 +41,6 @@ struct GemmArgs {
     int oT, oH, oW;             // output volume per batch item: M = NB*oT*oH*oW, row m = ((nb*oT+t)*oH+h)*oW+w
     int iT, iH, iW, iC;         // padded input volume dims (frames, rows, cols, channels per voxel)
     int stride_hw;              // spatial stride (1, or 2 for the down-sampling conv2d)
-    int stagger;                // main loop: 0 = one barrier per K tile (all waves in lock-step); 1 = ping-pong, one k-step per
-                                // slot; 2 = ping-pong, two k-steps per slot
     // split-K (launches with too few output tiles to fill 256 CUs: the deep, low-resolution VAE layers with K = 27*512):
     int ksplit;                 // 1 = off; otherwise grid = tiles * ksplit and workgroup (tile, slice) accumulates K tiles
                                 // [slice*nk/ksplit, (slice+1)*nk/ksplit) and stores its raw fp32 tile to part[slice][M][N]
@@ -407,7 +405,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
     stage(0, 0);
     drain_and_barrier();
 
-    if (p.stagger != 0) {
+    {
         // ---- "ping-pong" main loop -------------------------------------------------------------------------------
         // The two waves that share a SIMD (w and w+4) alternate roles every slot, phase-locked by s_barrier: while one
         // issues its MFMAs for KSPS k-steps (fragments already in registers) the other reads its next fragments from
@@ -517,138 +515,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
                 mma();                                             // last compute slot of the last tile
             }
         };
-        // ---- stagger 3: ping-pong with the fragment reads moved into the COMPUTE slots ---------------------------------------------
-        // Slot anatomy of the loop above (PMC, profiles/r02_gemm_pmc_anatomy.txt: 3 090 cycles per K tile against 2 048 of MFMAs): a
-        // load slot = 6 ds_read_b128 + up to 3 DMA pieces + the wait for the LDS data ≈ 400-450 cycles, while the partner's
-        // compute slot is 256 — the loader is the critical path of every slot.  Here a wave reads the fragments of k-step s+1 into
-        // a SECOND register set at the start of compute slot s (their latency hides under that slot's eight MFMAs; +24 VGPRs) and
-        // the load slots are left with the DMA pieces only (2 + the first k-step's fragment reads | 3 | 3 | none).  Barriers, buffer
-        // hand-over and vmcnt accounting are those of the loop above.
-        auto pingpong_pipe = [&]() {
-            bf16x8 wf[2][NT], xf[2][MT];
-            auto load_set = [&](int set, const char* base, int ks) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) wf[set][nt] = *(const bf16x8*)(base + w_row_base + nt * 4096 + chunk_off[ks]);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) xf[set][mt] = *(const bf16x8*)(base + x_row_base + mt * 4096 + chunk_off[ks]);
-            };
-            auto mma_set = [&](int set) {
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[set][nt], xf[set][mt], acc[mt][nt], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
-            };
-            // compute slot: the MFMAs of fragment set `cur` with the reads of k-step `ks` into set `nxt` placed BETWEEN them (an MFMA
-            // occupies the matrix pipe for 32 cycles but the issue port for a few: a read issued in its shadow costs nothing, a block
-            // of six reads ahead of the first MFMA delays the whole slot)
-            auto mma_load = [&](int cur, int nxt, const char* base, int ks) {
-                __builtin_amdgcn_s_setprio(1);
-                int li = 0;                                   // fragment loads issued so far: W fragments first, then X
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][nt], xf[cur][mt], acc[mt][nt], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    constexpr int PER = (NT + MT + MT - 1) / MT;      // reads per MFMA row group
-#pragma unroll
-                    for (int u = 0; u < PER; ++u, ++li) {
-                        if (li < NT) wf[nxt][li] = *(const bf16x8*)(base + w_row_base + li * 4096 + chunk_off[ks]);
-                        else if (li < NT + MT) xf[nxt][li - NT] = *(const bf16x8*)(base + x_row_base + (li - NT) * 4096 + chunk_off[ks]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                __builtin_amdgcn_s_setprio(0);
-            };
-            int tap_stage = GATHER ? __builtin_amdgcn_readfirstlane(p.tap_off[min(1, nk - 1) + k_first]) : 0;
-            int tap_ahead = 0;
-            constexpr int NP = A_ROUNDS + W_ROUNDS;
-            constexpr int CUT1 = NP / 4, CUT2 = CUT1 + (NP - CUT1 + 1) / 2;      // pieces [0,CUT1) | [CUT1,CUT2) | [CUT2,NP): 2 | 3 | 3 of 8
-            auto stage_range = [&](int kt, int buf, int r0, int r1) {
-                kt = min(kt, nk - 1) + k_first;
-                const unsigned a_soff = 2u * (unsigned)(GATHER ? tap_stage : kt * GEMM_BK), w_soff = 2u * (unsigned)(kt * GEMM_BK);
-                char* dst = lds_stage + buf * BUF_BYTES;
-#pragma unroll
-                for (int r = 0; r < A_ROUNDS; ++r)
-                    if (r >= r0 && r < r1) bglds16(a_rsrc, a_off[r], a_soff, dst + r * 8192);
-                if (w_active) {
-#pragma unroll
-                    for (int r = 0; r < W_ROUNDS; ++r)
-                        if (A_ROUNDS + r >= r0 && A_ROUNDS + r < r1) bglds16(w_rsrc, w_off[r], w_soff, dst + A_TILE + r * 8192);
-                }
-            };
-            auto slot_end = [&]() {
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            if (late_wave == 0) {
-                for (int kt = 0; kt < nk; ++kt) {
-                    const char* base = smem + (kt & 1) * BUF_BYTES;
-                    const int nb = (kt + 1) & 1;
-                    if (GATHER) tap_ahead = p.tap_off[min(kt + 2, nk - 1) + k_first];
-                    load_set(0, base, 0); stage_range(kt + 1, nb, 0, CUT1);                    // L0
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    slot_end();
-                    mma_load(0, 1, base, 1); slot_end();                                           // C0
-                    stage_range(kt + 1, nb, CUT1, CUT2); slot_end();                             // L1
-                    mma_load(1, 0, base, 2); slot_end();                                           // C1
-                    stage_range(kt + 1, nb, CUT2, NP); slot_end();                               // L2
-                    mma_load(0, 1, base, 3); slot_end();                                           // C2
-                    slot_end();                                                                  // L3
-                    mma_set(1);                                                                  // C3
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    slot_end();
-                    if (GATHER) tap_stage = __builtin_amdgcn_readfirstlane(tap_ahead);
-                }
-            } else {
-                for (int kt = 0; kt < nk; ++kt) {
-                    const char* base = smem + (kt & 1) * BUF_BYTES;
-                    const int nb = (kt + 1) & 1;
-                    if (GATHER) tap_ahead = p.tap_off[min(kt + 2, nk - 1) + k_first];
-                    if (kt > 0) mma_set(1);                                                      // C3 of the previous tile
-                    slot_end();
-                    load_set(0, base, 0); stage_range(kt + 1, nb, 0, CUT1);                    // L0
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    slot_end();
-                    mma_load(0, 1, base, 1); slot_end();                                           // C0
-                    stage_range(kt + 1, nb, CUT1, CUT2); slot_end();                             // L1
-                    mma_load(1, 0, base, 2); slot_end();                                           // C1
-                    stage_range(kt + 1, nb, CUT2, NP); slot_end();                               // L2
-                    mma_load(0, 1, base, 3);                                                       // C2
-                    slot_end();
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                  // L3
-                    slot_end();
-                    if (GATHER) tap_stage = __builtin_amdgcn_readfirstlane(tap_ahead);
-                }
-                mma_set(1);                                                                      // C3 of the last tile
-            }
-        };
-        if (p.stagger == 1) pingpong(std::integral_constant<int, 1>{});
-        else if (p.stagger == 3) pingpong_pipe();
-        else pingpong(std::integral_constant<int, 2>{});
-    } else
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
-        const char* base = smem + cur * BUF_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 wf[NT], xf[MT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) wf[nt] = *(const bf16x8*)(base + w_row_base + nt * 4096 + chunk_off[ks]);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) xf[mt] = *(const bf16x8*)(base + x_row_base + mt * 4096 + chunk_off[ks]);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
-        }
-        drain_and_barrier();
+        pingpong(std::integral_constant<int, 1>{});
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------------------

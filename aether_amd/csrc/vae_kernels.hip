@@ -185,7 +185,6 @@ extern "C" int aether_conv_gemm_bf16(const void* X, int NB, int iT, int iH, int 
     p.tap_off = tap_off;
     p.oT = oT; p.oH = oH; p.oW = oW; p.iT = iT; p.iH = iH; p.iW = iW; p.iC = iC; p.stride_hw = stride_hw;
     const bool wide = (flags & AETHER_GEMM_WIDE_STORE) != 0;
-    p.stagger = (flags >> 2) & 3;
     p.a_bytes = (unsigned)((size_t)NB * iT * iH * iW * iC * 2);
     p.w_bytes = (unsigned)((size_t)Cout * K * 2);
     dim3 block(512);

@@ -96,8 +96,8 @@ def unpatchify(Y, B, F, Cout, H, W, p):
     return out
 
 
-def qk_norm_rope(qkv, H, n_text, qn_w, qn_b, kn_w, kn_b, eps, cos, sin, q_scale, with_kmax=False):
-    """qkv bf16 [B,S,3*H*64] -> (Qh [B,H,S,64], Kh [B,H,S,64], Vt [B,H,64,Spad]) (+ kmax2 fp32 [B*H, Spad/64] = max ||k||^2 per 64-key tile)."""
+def qk_norm_rope(qkv, H, n_text, qn_w, qn_b, kn_w, kn_b, eps, cos, sin, q_scale):
+    """qkv bf16 [B,S,3*H*64] -> (Qh [B,H,S,64], Kh [B,H,S,64], Vt [B,H,64,Spad])."""
     _need_cuda(qkv)
     assert qkv.dtype == torch.bfloat16 and qkv.is_contiguous()
     B, S, _ = qkv.shape
@@ -105,16 +105,14 @@ def qk_norm_rope(qkv, H, n_text, qn_w, qn_b, kn_w, kn_b, eps, cos, sin, q_scale,
     Qh = torch.empty(B, H, S, 64, dtype=torch.bfloat16, device=qkv.device)
     Kh = torch.empty_like(Qh)
     Vt = torch.empty(B, H, 64, Spad, dtype=torch.bfloat16, device=qkv.device)
-    kmax2 = torch.empty(B * H, Spad // 64, dtype=torch.float32, device=qkv.device) if with_kmax else None
     rc = _lib.load().aether_qk_norm_rope(_lib.ptr(qkv), B, S, H, n_text, _lib.ptr(qn_w), _lib.ptr(qn_b), _lib.ptr(kn_w),
                                          _lib.ptr(kn_b), float(eps), _lib.ptr(cos), _lib.ptr(sin), float(q_scale),
-                                         _lib.ptr(Qh), _lib.ptr(Kh), _lib.ptr(Vt), Spad, _lib.ptr(kmax2),
-                                         _lib.current_stream())
+                                         _lib.ptr(Qh), _lib.ptr(Kh), _lib.ptr(Vt), Spad, _lib.current_stream())
     _lib.check(rc, "aether_qk_norm_rope")
-    return (Qh, Kh, Vt, kmax2) if with_kmax else (Qh, Kh, Vt)
+    return Qh, Kh, Vt
 
 
-def gemm_qkv_prep(A, W, bias, H, S, n_text, qn_w, qn_b, kn_w, kn_b, eps, cos, sin, q_scale, flags=5, rows=None):
+def gemm_qkv_prep(A, W, bias, H, S, n_text, qn_w, qn_b, kn_w, kn_b, eps, cos, sin, q_scale, flags=1, rows=None):
     """Fused qkv projection + q/k norm + RoPE + V transpose (aether_gemm_qkv_prep): A bf16 [B*S, K], W bf16 [3*H*64, K] ->
     (Qh [B,H,S,64], Kh [B,H,S,64], Vt [B,H,64,Spad]); `rows` < B*S prepares only the leading rows (B = 1).  The pad columns of Vt are
     zeroed here (aether_vt_pad_zero) so the result compares with `qk_norm_rope` directly."""
@@ -135,15 +133,14 @@ def gemm_qkv_prep(A, W, bias, H, S, n_text, qn_w, qn_b, kn_w, kn_b, eps, cos, si
     return Qh, Kh, Vt
 
 
-def flash_attn_fwd(Qh, Kh, Vt, flags=0, kmax2=None):
+def flash_attn_fwd(Qh, Kh, Vt, flags=0):
     """Qh,Kh [B,H,S,64] (softmax scale x log2(e) folded into Qh: _lib.ATTN_Q_SCALE), Vt [B,H,64,Spad] -> O [B,S,H*64].
-    kmax2 fp32 [B*H, Spad/64]: upper bound of ||k||^2 per (batch, head, 64-key tile) enabling the bounded-score soft-max path."""
+    flags: AETHER_GEMM_WIDE_STORE | AETHER_ATTN_EXACT_MAX (the conservative path alone)."""
     _need_cuda(Qh, Kh, Vt)
     B, H, S, d = Qh.shape
     assert d == 64 and Qh.is_contiguous() and Kh.is_contiguous() and Vt.is_contiguous()
     Spad = Vt.shape[-1]
     O = torch.empty(B, S, H * 64, dtype=torch.bfloat16, device=Qh.device)
-    rc = _lib.load().aether_flash_attn_fwd(_lib.ptr(Qh), _lib.ptr(Kh), _lib.ptr(Vt), _lib.ptr(O), B, H, S, Spad, _lib.ptr(kmax2), flags,
-                                           _lib.current_stream())
+    rc = _lib.load().aether_flash_attn_fwd(_lib.ptr(Qh), _lib.ptr(Kh), _lib.ptr(Vt), _lib.ptr(O), B, H, S, Spad, flags, _lib.current_stream())
     _lib.check(rc, "aether_flash_attn_fwd")
     return O

@@ -50,7 +50,7 @@ class AetherTransformer3D:
     """Duck-types the members the reference pipeline touches: `config`, `__call__(hidden_states=, encoder_hidden_states=,
     timestep=, ofs=, image_rotary_emb=, attention_kwargs=, return_dict=False)[0]`, `from_pretrained`, `to`, `dtype`."""
 
-    def __init__(self, config: Optional[dict] = None, device: str = "cuda", flags: int = _lib.AETHER_GEMM_WIDE_STORE | _lib.AETHER_GEMM_PINGPONG | _lib.AETHER_ATTN_PAIR_PIPELINE | _lib.AETHER_ATTN_QREG):
+    def __init__(self, config: Optional[dict] = None, device: str = "cuda", flags: int = _lib.AETHER_GEMM_WIDE_STORE):
         cfg = dict(_CONFIG_DEFAULTS)
         cfg.update(config or {})
         self.config = SimpleNamespace(**cfg)

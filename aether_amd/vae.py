@@ -115,7 +115,7 @@ class _Resnet:
 
 
 class AetherVAE:
-    def __init__(self, config: Optional[dict] = None, device="cuda", flags: int = _lib.AETHER_GEMM_WIDE_STORE | _lib.AETHER_GEMM_PINGPONG):
+    def __init__(self, config: Optional[dict] = None, device="cuda", flags: int = _lib.AETHER_GEMM_WIDE_STORE):
         cfg = dict(_CONFIG_DEFAULTS)
         cfg.update(config or {})
         cfg["block_out_channels"] = tuple(cfg["block_out_channels"])

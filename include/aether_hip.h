@@ -46,16 +46,12 @@ int aether_check_device(void);
 #define AETHER_EPI_BIAS_GELU 1     /* C = gelu_tanh(A·Wᵀ + bias)                                 */
 #define AETHER_EPI_BIAS_GATE_RES 2 /* C = R + gate[b(m),type(m),:] ⊙ (A·Wᵀ + bias)               */
 #define AETHER_GEMM_WIDE_STORE 1   /* flags bit: 16-byte stores through a half-wave exchange      */
-#define AETHER_GEMM_PINGPONG 4      /* flags bit 2: ping-pong main loop — the two waves that share a SIMD alternate
-                                      "read fragments from LDS" and "issue MFMAs" slots, phase-locked by s_barrier, LDS-DMA
-                                      issued in the MFMA shadow (+8..12 % over the lock-step loop on MI355X)              */
-#define AETHER_GEMM_PINGPONG2 8     /* flags bit 3 (instead of bit 2): same with two k-steps per slot                     */
-#define AETHER_GEMM_4WAVE 1024      /* flags bit 10: four-wave main loop (one wave per SIMD, 128x128 register tile each, LDS reads and
-                                      LDS-DMA issued between the wave's own MFMAs, one barrier per K tile); full rounds only, the
-                                      split-K tail launch keeps the eight-wave kernel                                          */
-#define AETHER_GEMM_PERSISTENT 32768 /* flags bit 15 (with bit 2): persistent grid — ceil(tiles / rounds) <= 256 workgroups (236 for the DiT shapes) that
-                                        each own whole tiles; the K tiles of consecutive output tiles form one stream through the LDS buffers (the
-                                        next tile's first operands are requested under the current tile's last k-steps); no tail launch        */
+#define AETHER_GEMM_SPLIT_LONE_TAIL 2 /* flags bit 1: a launch of 64..128 tiles (less than ONE round of 256) with K >= 2048 also splits its K loop
+                                         (fp32 partials + finalize: a different summation order) — only the fused-qkv remainder of
+                                         aether_dit_forward asks for it                                                           */
+/* Main loop (one; the lock-step, two-k-steps-per-slot, fragment-reads-in-the-compute-slot, four-wave and persistent-grid loops measured in
+ * rounds 1-3 are recorded in profiles/r0*_gemm_*): "ping-pong" — the two waves that share a SIMD alternate "read fragments from LDS + issue
+ * the next tile's LDS-DMA" and "issue MFMAs" slots, phase-locked by s_barrier. */
 
 /* C[M,N] = epi(A[M,K] · W[N,K]ᵀ), bf16 in / bf16 out / fp32 accumulate on MFMA.
  * Replaces nn.Linear in CogVideoXBlock / CogVideoXPatchEmbed / proj_out under P:865-875
@@ -105,12 +101,10 @@ int aether_unpatchify(const void* Y, int ldy, void* out, int B, int F, int Cout,
  * qkv bf16 [B,S,3*H*64] (q | k | v thirds) -> Qh,Kh bf16 [B,H,S,64] and Vt bf16 [B,H,64,Spad]
  * (V transposed, Spad = roundup(S,64), pad columns zeroed).  Rows [0,n_text) of each batch are text rows
  * (no RoPE); cos,sin fp32 [S-n_text, 64].  Q is additionally multiplied by q_scale in fp32 before its single rounding
- * to bf16; the attention kernel expects q_scale = log2(e)/sqrt(64) (scores in the log2 domain).
- * kmax2 (fp32 [B*H, Spad/64], may be NULL): receives max ||k||^2 over every 64-key tile of every (batch, head), taken on the
- * rounded bf16 keys; it feeds the bounded-score path of aether_flash_attn_fwd. */
+ * to bf16; the attention kernel expects q_scale = log2(e)/sqrt(64) (scores in the log2 domain). */
 int aether_qk_norm_rope(const void* qkv, int B, int S, int H, int n_text, const float* qn_w, const float* qn_b,
                         const float* kn_w, const float* kn_b, float eps, const float* cos_t, const float* sin_t,
-                        float q_scale, void* Qh, void* Kh, void* Vt, int Spad, float* kmax2, void* stream);
+                        float q_scale, void* Qh, void* Kh, void* Vt, int Spad, void* stream);
 
 /* The same for the tokens s >= first_token (a multiple of 64) only — the tail rows of a forward whose leading rows were prepared in the
  * epilogue of aether_gemm_qkv_prep.  Covers the ragged last 64-token tile, i.e. also zeroes the pad columns of Vt. */
@@ -127,7 +121,7 @@ int aether_vt_pad_zero(void* Vt, int rows, int S, int Spad, void* stream);
  * v: transposed store -> Vt [B,H,64,Spad] (pad columns NOT written: aether_vt_pad_zero / aether_qk_norm_rope_tail).  M = rows of whole
  * batch items, or the leading rows of one (the caller may keep a partly filled last round of tiles for the un-fused path).  Replaces
  * to_q / to_k / to_v + norm_q / norm_k + apply_rotary_emb of diffusers' CogVideoXAttnProcessor2_0 (reference call P:865-875).
- * flags: AETHER_GEMM_WIDE_STORE, AETHER_GEMM_PINGPONG*. */
+ * flags: AETHER_GEMM_WIDE_STORE. */
 int aether_gemm_qkv_prep(const void* A, int lda, const void* W, int ldw, const float* bias, int M, int heads, int K, int S, int n_text,
                          const float* qn_w, const float* qn_b, const float* kn_w, const float* kn_b, float eps, const float* cos_t,
                          const float* sin_t, float q_scale, void* Qh, void* Kh, void* Vt, int Spad, int flags, void* stream);
@@ -135,30 +129,12 @@ int aether_gemm_qkv_prep(const void* A, int lda, const void* W, int ldw, const f
 #define AETHER_DIT_FUSE_QKV_PREP 65536 /* flags bit 16 (aether_dit_forward): q/k norm + RoPE + V transpose in the qkv GEMM's epilogue
                                           (aether_gemm_qkv_prep) instead of a pass of their own                                     */
 
-#define AETHER_ATTN_PIPELINED 16  /* flags bit 4: software-pipelined kernel (one workgroup per CU; inside each wave the soft-max
-                                     of tile j is interleaved with the MFMAs of P·V(j-1) and K(j+1)·Qᵀ)                    */
-#define AETHER_ATTN_EXACT_MAX 32  /* flags bit 5: conservative path only: no shift-0 sweep, no bound table — every row's shift is a true
-                                     score maximum from its first tile on (generic tiles with the a-posteriori check)               */
-#define AETHER_ATTN_INTERLEAVE 256 /* flags bit 8: tiles that pass the a-priori guard (needs kmax2) interleave the soft-max VALU with
-                                      the wave's own MFMAs, one tile per iteration                                                  */
-#define AETHER_ATTN_PAIR_PIPELINE 512 /* flags bit 9 (default): two tiles per iteration with each half's soft-max spread over its
-                                        neighbours' MFMAs, run OPTIMISTICALLY with shift 0; a workgroup whose finished rows show that
-                                        some exp2 left fp32's range starts over on the conservative path                          */
-#define AETHER_ATTN_TAIL_SPLIT 64 /* flags bit 6: workgroups beyond the last full round of 512 run as 128-row workgroups (2nd launch) */
-#define AETHER_ATTN_DOT2_SUM 2048 /* flags bit 11: row sums from the ROUNDED bf16 P pairs by v_dot2c_f32_bf16 against (1,1): one VALU
-                                     issue per two scores instead of two adds; numerator and denominator then round alike           */
-#define AETHER_ATTN_QREG 4096     /* flags bit 12 (with bit 9): the tile-pair loop keeps the Q fragments in registers (no shift vector to hold
-                                     there) instead of re-reading them from LDS                                                       */
-#define AETHER_ATTN_ROWS64 8192   /* flags bit 13: 64 query rows per wave (4 waves per 256-row workgroup, 2 waves per SIMD): every K / V fragment
-                                     read feeds two MFMAs, Q in registers; optimistic shift-0 sweep + classic online soft-max on redo       */
-#define AETHER_ATTN_WG512 16384   /* flags bit 14 (with bit 13): 8 such waves = 512 query rows per workgroup, one workgroup per CU: half the LDS-DMA
-                                     instructions per MFMA                                                                                */
+#define AETHER_ATTN_EXACT_MAX 32  /* flags bit 5: conservative path only: no shift-0 sweep — every row's shift is a true score maximum from
+                                     its first tile on (generic tiles with the a-posteriori check); data-independent cost           */
 
 /* Non-causal flash attention, head_dim 64: O[b,s,h*64+d] = softmax_2(Qh·Khᵀ)·V where softmax_2 uses base 2, i.e.
  * Qh must carry softmax_scale·log2(e) (see aether_qk_norm_rope).  Replaces F.scaled_dot_product_attention in
  * CogVideoXAttnProcessor2_0.  Qh,Kh [B,H,S,64], Vt [B,H,64,Spad], O bf16 [B,S,H*64].
- * kmax2 (fp32 [B*H, Spad/64] or NULL): upper bound of ||k||^2 per (batch, head, 64-key tile); read only by AETHER_ATTN_INTERLEAVE
- * and AETHER_ATTN_PIPELINED — the default path needs no bound.
  * Soft-max = exact on every path (soft-max is invariant under any per-row shift; the running maximum of the online algorithm only
  * keeps exp2 in range).  Conservative path: each row keeps a shift m that is a true score maximum (of its first tile, then of any
  * tile that forced a refresh); a tile is exponentiated against m directly — no tile maximum, no subtraction (m rides in the C
@@ -167,10 +143,8 @@ int aether_gemm_qkv_prep(const void* A, int lda, const void* W, int ldw, const f
  * the same with shift 0 for the whole sweep in a two-tile software pipeline; finished rows whose sum is not in [2^-100, inf) or
  * whose accumulators are not finite make the WORKGROUP redo its sweep on the conservative path.  Either way the results are those
  * of an exact fp32 soft-max; only speed depends on the data (|log2-domain score| > 100 is needed to leave the fast path).
- * (The software-pipelined variant keeps the round-1 rule: no-maximum path iff ||q||·max||k|| <= 96 for the whole head.)
- * flags: AETHER_GEMM_WIDE_STORE (16-byte epilogue stores), AETHER_ATTN_*. */
-int aether_flash_attn_fwd(const void* Qh, const void* Kh, const void* Vt, void* O, int B, int H, int S, int Spad,
-                          const float* kmax2, int flags, void* stream);
+ * flags: AETHER_GEMM_WIDE_STORE (16-byte epilogue stores), AETHER_ATTN_EXACT_MAX. */
+int aether_flash_attn_fwd(const void* Qh, const void* Kh, const void* Vt, void* O, int B, int H, int S, int Spad, int flags, void* stream);
 
 /* Element-wise tail of one denoise step in ONE pass (aetherv1_pipeline_cogvideox.py:876-916): fp32 cast of the noise prediction (P:877),
  * classifier-free-guidance combine uncond + g·(cond − uncond) when nb = 2 (P:895-899), CogVideoXDPMScheduler.step for v-prediction

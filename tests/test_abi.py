@@ -30,7 +30,7 @@ def test_error_reporting_without_gpu(hip_lib):
     assert rc == -2 and b"multiple of 64" in hip_lib.aether_last_error()
     rc = hip_lib.aether_layernorm_modulate(16, 8, 16, 8, 4, 300, 1e-5, None, None, None, None, None, None, 0, 0, 0, None)
     assert rc == -2
-    rc = hip_lib.aether_flash_attn_fwd(4096, 4096, 4096, 4096, 1, 2, 100, 100, None, 0, None)      # Spad not a multiple of 64
+    rc = hip_lib.aether_flash_attn_fwd(4096, 4096, 4096, 4096, 1, 2, 100, 100, 0, None)      # Spad not a multiple of 64
     assert rc == -2 and b"Spad" in hip_lib.aether_last_error()
     rc = hip_lib.aether_conv_gemm_bf16(4096, 1, 3, 4, 4, 64, 1, 2, 2, 3, 4096, 27, 4096, 64, 4096, 64, None, None, 0, None, 0, 0, None)
     assert rc == -2                                                                                   # stride must be 1 or 2

@@ -28,7 +28,7 @@ def _bf16_close(got, ref_fp32, what, rel=6e-3, max_ulp_frac=2.0):
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 256), (300, 256, 128), (1000, 512, 3072), (226, 512, 4096), (37, 224, 512)])
-@pytest.mark.parametrize("flags", [0, 1, 1 | 4, 1 | 8, 4, 1 | 12, 1024, 1025, 32768 | 5, 32768 | 4])     # bit 15: persistent grid; bit 0: 16-byte stores; bits 2/3: ping-pong main loop (1 / 2 k-steps per slot; both: fragment reads in the compute slots); bit 10: four-wave loop
+@pytest.mark.parametrize("flags", [0, 1])     # bit 0: 16-byte stores through a half-wave exchange
 def test_gemm_bias(cuda, hip_lib, M, N, K, flags):
     from aether_amd import ops
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
@@ -52,7 +52,7 @@ def test_gemm_transpose_detecting(cuda, hip_lib):
     assert torch.equal(out.cpu().float(), W.float().t())
 
 
-@pytest.mark.parametrize("flags", [0, 5, 13, 1025, 32768 | 5])
+@pytest.mark.parametrize("flags", [0, 1])
 def test_gemm_gelu(cuda, hip_lib, flags):
     from aether_amd import ops
     g = torch.Generator().manual_seed(5)
@@ -66,7 +66,7 @@ def test_gemm_gelu(cuda, hip_lib, flags):
     _bf16_close(out, ref, "gemm+gelu")
 
 
-@pytest.mark.parametrize("flags", [0, 5, 9, 13, 1024, 1025, 32768 | 5])
+@pytest.mark.parametrize("flags", [0, 1])
 def test_gemm_gate_residual_inplace(cuda, hip_lib, flags):
     from aether_amd import ops
     g = torch.Generator().manual_seed(6)
@@ -91,7 +91,7 @@ def test_gemm_gate_residual_inplace(cuda, hip_lib, flags):
     _bf16_close(x, ref, "gemm+gate+res")
 
 
-@pytest.mark.parametrize("gflags", [5, 9, 13, 1029])
+@pytest.mark.parametrize("gflags", [0, 1])
 @pytest.mark.parametrize("epi", ["bias", "gelu", "gate_res"])
 def test_gemm_tail_split_k(cuda, hip_lib, epi, gflags):
     """17 x 16 = 272 tiles = one full round of 256 + 16: with scratch the 16 tail tiles run as a second launch whose K loop
@@ -135,14 +135,12 @@ def test_gemm_tail_split_k(cuda, hip_lib, epi, gflags):
 
 
 @pytest.mark.parametrize("epi", ["bias", "gelu", "gate_res"])
-@pytest.mark.parametrize("M,N,K", [(17 * 256 - 40, 4096, 1024), (13 * 256 - 40, 21 * 256, 384), (3 * 600, 1024, 320)])
-def test_gemm_persistent_grid(cuda, hip_lib, epi, M, N, K):
-    """AETHER_GEMM_PERSISTENT: ceil(tiles / rounds) workgroups that each walk several output tiles as ONE stream of K tiles (the next
-    tile's first operands are requested under the current tile's last k-steps; ragged last row tile; workgroups with unequal tile
-    counts: 272 tiles on 136 workgroups, 273 on 137 — the last one owns a single tile —, 32 on 32 with an odd number of K tiles).  Same arithmetic and K order as the one-tile-per-workgroup kernel:
-    BIT-identical to it, and run to run."""
+def test_gemm_lone_tail_split_k(cuda, hip_lib, epi):
+    """AETHER_GEMM_SPLIT_LONE_TAIL (flag 2, what aether_dit_forward passes for the un-fused remainder of the fused qkv projection): a launch of
+    64..128 tiles — less than ONE round — with K >= 2048 splits its K loop as well.  Without the flag the same call is a single launch."""
     from aether_amd import ops
-    g = torch.Generator().manual_seed(M + N)
+    g = torch.Generator().manual_seed(23)
+    M, N, K = 5 * 256 - 30, 16 * 256, 2048                              # 80 tiles, 32 K tiles -> split over 3 workgroups each
     A = torch.randn(M, K, generator=g).to(torch.bfloat16)
     W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
     bias = torch.randn(N, generator=g)
@@ -155,24 +153,24 @@ def test_gemm_persistent_grid(cuda, hip_lib, epi, M, N, K):
     else:
         R = torch.randn(M, N, generator=g).to(torch.bfloat16)
         gate = torch.randn(1, 2 * N, generator=g)
-        n_text = 100
-        gsel = torch.where((torch.arange(M) < n_text)[:, None], gate[0, N:], gate[0, :N])
+        gsel = torch.where((torch.arange(M) < 100)[:, None], gate[0, N:], gate[0, :N])
         ref, code = R.float() + gsel * y, ops.AETHER_EPI_BIAS_GATE_RES
         gc = gate.to(cuda)
-        kw = dict(gate_vid=gc[:, :N], gate_txt=gc[:, N:], rows_per_batch=M, n_text=n_text)
-    ws = torch.empty(16 << 20, dtype=torch.float32, device=cuda)      # 64 MiB of split-K scratch
-    for use_ws in (None, ws):        # without scratch: balanced grid, no tail; with: 256 workgroups over the full rounds + the split-K tail launch
-        outs = []
-        for flags in (5, 32768 | 5, 32768 | 5):
-            if epi == "gate_res":
-                x = R.to(cuda).clone()
-                ops.gemm_bf16(A.to(cuda), W.to(cuda), bias.to(cuda), code, R=x, out=x, flags=flags, splitk_ws=use_ws, **kw)      # in place on the residual
-                outs.append(x)
-            else:
-                outs.append(ops.gemm_bf16(A.to(cuda), W.to(cuda), bias.to(cuda), code, flags=flags, splitk_ws=use_ws))
-        torch.cuda.synchronize()
-        _bf16_close(outs[1], ref, f"persistent gemm {epi}")
-        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+        kw = dict(gate_vid=gc[:, :N], gate_txt=gc[:, N:], rows_per_batch=M, n_text=100)
+    ws = torch.empty(16 << 20, dtype=torch.float32, device=cuda)
+    outs = []
+    for flags in (1, 1 | 2, 1 | 2):
+        if epi == "gate_res":
+            x = R.to(cuda).clone()
+            ops.gemm_bf16(A.to(cuda), W.to(cuda), bias.to(cuda), code, R=x, out=x, flags=flags, splitk_ws=ws, **kw)
+            outs.append(x)
+        else:
+            outs.append(ops.gemm_bf16(A.to(cuda), W.to(cuda), bias.to(cuda), code, flags=flags, splitk_ws=ws))
+    torch.cuda.synchronize()
+    for o in outs:
+        _bf16_close(o, ref, f"gemm lone-tail split-K {epi}")
+    assert torch.equal(outs[1], outs[2])                               # deterministic
+    assert not torch.equal(outs[0], outs[1])                           # the flag did change the summation order (i.e. the split ran)
 
 
 def test_gemm_rejects_bad_shapes(cuda, hip_lib):
@@ -274,31 +272,16 @@ def test_qk_norm_rope(cuda, hip_lib, B, H, S, n_text):
     qkv, qn_w, qn_b, kn_w, kn_b, cos, sin = _attn_inputs(B, H, S, n_text, 11)
     q, k, v = _qk_ref(qkv, H, n_text, qn_w, qn_b, kn_w, kn_b, cos, sin)
     c = lambda t: t.to(cuda)
-    Qh, Kh, Vt, kmax2 = ops.qk_norm_rope(c(qkv), H, n_text, c(qn_w), c(qn_b), c(kn_w), c(kn_b), 1e-6, c(cos), c(sin),
-                                         ATTN_Q_SCALE, with_kmax=True)
+    Qh, Kh, Vt = ops.qk_norm_rope(c(qkv), H, n_text, c(qn_w), c(qn_b), c(kn_w), c(kn_b), 1e-6, c(cos), c(sin), ATTN_Q_SCALE)
     torch.cuda.synchronize()
     _bf16_close(Qh, q * ATTN_Q_SCALE, "Qh")
     _bf16_close(Kh, k, "Kh")
     assert torch.equal(Vt.cpu()[..., :S].float(), v.transpose(2, 3))      # transpose only: bit exact
     assert (Vt.cpu()[..., S:] == 0).all()
-    # max ||k||^2 per (batch, head, 64-key tile), reduced from the bf16 Kh the attention kernel reads (1e-5: fp32 summation order)
-    Spad = Vt.shape[-1]
-    n2 = torch.zeros(B * H, Spad)
-    n2[:, :S] = (Kh.float().cpu() ** 2).sum(-1).reshape(B * H, S)
-    ref_kmax2 = n2.reshape(B * H, Spad // 64, 64).amax(-1)
-    assert torch.allclose(kmax2.cpu(), ref_kmax2, rtol=1e-5), (kmax2.cpu(), ref_kmax2)
-    # without the optional output the signature is unchanged
-    Qh2, Kh2, Vt2 = ops.qk_norm_rope(c(qkv), H, n_text, c(qn_w), c(qn_b), c(kn_w), c(kn_b), 1e-6, c(cos), c(sin), ATTN_Q_SCALE)
-    torch.cuda.synchronize()
-    assert torch.equal(Qh2, Qh) and torch.equal(Kh2, Kh) and torch.equal(Vt2, Vt)
 
 
-# attention kernel variants: lock-step (narrow / wide store), lock-step with the tail split (64: with <= 512 workgroups
-# everything then runs as 128-row workgroups), software-pipelined (narrow / wide store)
-# 256: in-wave interleaved steady-state tiles (a-priori guard); 512: optimistic tile-pair pipeline (+ redo); 2048: row sums by v_dot2c_f32_bf16
-# 4096: Q fragments in registers inside the tile-pair loop; 8192: 64-rows-per-wave kernel (optimistic sweep + classic online soft-max on redo)
-ATTN_FLAGS = [0, 1, 64 | 1, 16, 16 | 1, 256, 256 | 1, 512, 512 | 1, 2048 | 1, 2048 | 256 | 1, 2048 | 512 | 1, 2048 | 512, 4096 | 512 | 1,
-              4096 | 2048 | 512 | 1, 8192, 8192 | 1, 8192 | 2048 | 1, 16384 | 8192 | 1, 16384 | 8192]   # 16384: 512-row workgroups
+# attention paths: the default (optimistic tile-pair sweep, conservative redo) with narrow / wide stores, and the conservative path alone (32)
+ATTN_FLAGS = [0, 1, 32, 32 | 1]
 
 
 def _attn_case(B, H, S, seed, q_gain=1.0):
@@ -315,29 +298,23 @@ def _attn_case(B, H, S, seed, q_gain=1.0):
     # fp32 reference on the SAME rounded operands: softmax over base 2 of qb.kb
     ref = torch.nn.functional.scaled_dot_product_attention(qb.float(), kb.float(), vb.float(), scale=math.log(2.0))
     ref = ref.transpose(1, 2).reshape(B, S, H * 64)
-    # per-(batch, head, 64-key tile) bound, as aether_qk_norm_rope emits it (here simply the head maximum everywhere)
-    kmax2 = (kb.float() ** 2).sum(-1).amax(-1).reshape(-1, 1).repeat(1, Spad // 64).contiguous()
-    return qb, kb, vt, ref, kmax2
+    return qb, kb, vt, ref
 
 
 @pytest.mark.parametrize("B,H,S", [(1, 2, 64), (1, 2, 256), (2, 3, 300), (1, 1, 1000), (1, 2, 1541), (1, 1, 4100)])
 @pytest.mark.parametrize("flags", ATTN_FLAGS)
-@pytest.mark.parametrize("bounded", [False, True])
-def test_flash_attention(cuda, hip_lib, B, H, S, flags, bounded):
-    """bounded=True hands the kernel max||k||^2: with N(0,1) operands ||q'||·||k|| ~ 0.18·8·8·(1.3) < 64, so every wave
-    takes the no-maximum soft-max; bounded=False is the exact online soft-max.  Both must match the fp32 reference."""
+def test_flash_attention(cuda, hip_lib, B, H, S, flags):
     from aether_amd import ops
-    qb, kb, vt, ref, kmax2 = _attn_case(B, H, S, S)
-    out = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags, kmax2=kmax2.to(cuda) if bounded else None)
+    qb, kb, vt, ref = _attn_case(B, H, S, S)
+    out = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags)
     torch.cuda.synchronize()
     # P is rounded to bf16 before P·V (as every flash kernel does): 1.5e-2 relative L2, 4 bf16 ulps of the scale
-    _bf16_close(out, ref, f"flash S={S} flags={flags} bounded={bounded}", rel=1.5e-2, max_ulp_frac=4.0)
+    _bf16_close(out, ref, f"flash S={S} flags={flags}", rel=1.5e-2, max_ulp_frac=4.0)
 
 
-@pytest.mark.parametrize("flags", [1, 17])
-def test_flash_attention_bounded_near_the_limit(cuda, hip_lib, flags):
-    """Scores spread over almost the whole admitted range (||q||·||k|| = 90 in the log2 domain, so p = exp2(s) spans
-    2^-90 .. 2^90 with no running maximum): still the fp64 soft-max to bf16 accuracy, no overflow / underflow."""
+def test_flash_attention_near_the_fp32_range(cuda, hip_lib):
+    """Scores spread over +-90 in the log2 domain (p = exp2(s) spans 2^-90 .. 2^90 with shift 0): inside what the optimistic sweep may keep
+    (no redo), still the fp64 soft-max to bf16 accuracy; the conservative path agrees."""
     from aether_amd import ops
     g = torch.Generator().manual_seed(90)
     B, H, S = 1, 2, 1000
@@ -350,47 +327,34 @@ def test_flash_attention_bounded_near_the_limit(cuda, hip_lib, flags):
     ref = torch.softmax((qb.double() @ kb.double().transpose(-1, -2)) * math.log(2.0), dim=-1) @ vb.double()
     vt = torch.zeros(B, H, 64, 1024, dtype=torch.bfloat16)
     vt[..., :S] = vb.transpose(2, 3)
-    kmax2 = (kb.float() ** 2).sum(-1).amax(-1).reshape(-1, 1).repeat(1, 16).contiguous()
-    assert float((qb.float().norm(dim=-1).max() * kmax2.max().sqrt())) < 96.0 / 1.02 ** 0.5      # inside the bounded path
-    out = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags, kmax2=kmax2.to(cuda))
-    exact = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags | 32, kmax2=kmax2.to(cuda))
+    out = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=1)
+    exact = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=1 | 32)
     torch.cuda.synchronize()
     r = ref.float().transpose(1, 2).reshape(B, S, H * 64)
-    _bf16_close(out, r, "flash bounded near the limit", rel=1.5e-2, max_ulp_frac=4.0)
-    _bf16_close(exact, r, "flash exact near the limit", rel=1.5e-2, max_ulp_frac=4.0)
+    _bf16_close(out, r, "flash optimistic near the limit", rel=1.5e-2, max_ulp_frac=4.0)
+    _bf16_close(exact, r, "flash conservative near the limit", rel=1.5e-2, max_ulp_frac=4.0)
 
 
 @pytest.mark.parametrize("flags", ATTN_FLAGS)
-def test_flash_attention_bound_gate(cuda, hip_lib, flags):
-    """Scores far outside the bounded-score limit (|s| up to ~400 in the log2 domain): exp2(s) without the running
-    maximum would overflow, so the kernel must fall back to the exact soft-max even though a bound was supplied —
-    per wave: rows 0-255 are tame (their waves may take the fast path), rows 256+ are hot."""
+def test_flash_attention_hot_rows_redo(cuda, hip_lib, flags):
+    """Scores far outside fp32's exp2 range (|s| up to ~400 in the log2 domain) for the query rows 256+: their workgroups' optimistic sweeps
+    fail the end-of-sweep vote and are redone on the conservative path; rows 0-255 keep the fast path."""
     from aether_amd import ops
-    qb, kb, vt, _, kmax2 = _attn_case(1, 2, 640, 5)
+    qb, kb, vt, _ = _attn_case(1, 2, 640, 5)
     qb[:, :, 256:] = (qb[:, :, 256:].float() * 40.0).to(torch.bfloat16)
     vb = vt[..., :640].transpose(2, 3)
     ref = torch.nn.functional.scaled_dot_product_attention(qb.float(), kb.float(), vb.float(), scale=math.log(2.0))
-    out = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags, kmax2=kmax2.to(cuda))
+    out = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags)
     torch.cuda.synchronize()
-    _bf16_close(out, ref.transpose(1, 2).reshape(1, 640, 128), f"flash bound gate flags={flags}", rel=1.5e-2, max_ulp_frac=4.0)
-    # AETHER_ATTN_EXACT_MAX = the conservative path: generic tiles (true-maximum shift, a-posteriori check, no bound table) with the row
-    # sums by v_dot2c — what every variant but the optimistic sweeps (512, 8192) runs when no bound is supplied and 2048 is set: bit-identical
-    a = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags | 32, kmax2=kmax2.to(cuda))
-    b = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags | 2048, kmax2=None)
-    torch.cuda.synchronize()
-    if not flags & (512 | 8192):
-        assert torch.equal(a, b)
-    _bf16_close(a, ref.transpose(1, 2).reshape(1, 640, 128), f"flash conservative path flags={flags}", rel=1.5e-2, max_ulp_frac=4.0)
-    _bf16_close(b, ref.transpose(1, 2).reshape(1, 640, 128), f"flash no bound table flags={flags}", rel=1.5e-2, max_ulp_frac=4.0)
+    _bf16_close(out, ref.transpose(1, 2).reshape(1, 640, 128), f"flash hot rows flags={flags}", rel=1.5e-2, max_ulp_frac=4.0)
 
 
 @pytest.mark.parametrize("pattern", ["hot_rows", "late_hot_keys", "early_peak", "cold_start", "span_edge", "all_cold", "hot_tail"])
-@pytest.mark.parametrize("flags", [0, 1, 256, 257, 513, 2048 | 1, 2048 | 257, 2048 | 513, 4096 | 513, 8192 | 1, 8192 | 2048 | 1, 16384 | 8192 | 1])
+@pytest.mark.parametrize("flags", [0, 1])
 def test_flash_attention_guarded_shift(cuda, hip_lib, flags, pattern):
     """Exactness of every soft-max path on score ranges far beyond fp32's exp2 range, in every order, against an fp64 soft-max.
-    Conservative path (generic tiles): per-row shift m = a true score maximum; a tile is exponentiated against the standing m and
-    checked afterwards (partial sum > 2^100 -> classic online step on the scores still held).  Interleaved path (256): a-priori
-    guard ||q||·max_tile||k|| <= m + 100 from the per-tile bounds (as aether_qk_norm_rope emits them).  Tile-pair pipeline (512):
+    Conservative path (generic tiles; `flags | 32`): per-row shift m = a true score maximum; a tile is exponentiated against the standing m
+    and checked afterwards (partial sum > 2^100 -> classic online step on the scores still held).  Default (tile-pair pipeline):
     shift 0 for the whole sweep; rows whose sums / accumulators left fp32's range send their WORKGROUP through the conservative path
     again (hot_rows, early_peak, late_hot_keys overflow; all_cold underflows to 0; hot_tail overflows in the generic tail tiles)."""
     from aether_amd import ops
@@ -425,15 +389,12 @@ def test_flash_attention_guarded_shift(cuda, hip_lib, flags, pattern):
     Spad = (S + 63) // 64 * 64
     vt = torch.zeros(B, H, 64, Spad, dtype=torch.bfloat16)
     vt[..., :S] = vb.transpose(2, 3)
-    n2 = torch.zeros(B * H, Spad)
-    n2[:, :S] = (kb.float() ** 2).sum(-1).reshape(B * H, S)
-    kmax2 = n2.reshape(B * H, Spad // 64, 64).amax(-1).contiguous()
-    out = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags, kmax2=kmax2.to(cuda))
-    every = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags | 32, kmax2=kmax2.to(cuda))   # refresh on every tile
+    out = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags)
+    every = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags | 32)                          # the conservative path alone
     torch.cuda.synchronize()
     assert torch.isfinite(out.float()).all()
     _bf16_close(out, ref, f"flash guarded shift {pattern}", rel=1.5e-2, max_ulp_frac=4.0)
-    _bf16_close(every, ref, f"flash refresh-every-tile {pattern}", rel=1.5e-2, max_ulp_frac=4.0)
+    _bf16_close(every, ref, f"flash conservative {pattern}", rel=1.5e-2, max_ulp_frac=4.0)
 
 
 @pytest.mark.parametrize("flags", ATTN_FLAGS)
@@ -456,29 +417,15 @@ def test_flash_attention_online_max_jump(cuda, hip_lib, flags):
     _bf16_close(out, ref.transpose(1, 2).reshape(B, S, 64), f"flash max-jump flags={flags}", rel=1.5e-2, max_ulp_frac=4.0)
 
 
-def test_flash_attention_two_launches(cuda, hip_lib):
-    """31 heads x 17 query blocks = 527 workgroups: 512 run as 256-row workgroups, the last 15 as 30 128-row workgroups
-    (the second launch) — both halves against the fp32 reference, and bit-identical to the single-launch kernel."""
-    from aether_amd import ops
-    qb, kb, vt, ref, kmax2 = _attn_case(1, 31, 4100, 31)
-    for bound in (None, kmax2.to(cuda)):
-        out = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=1 | 64, kmax2=bound)
-        one = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=1, kmax2=bound)
-        torch.cuda.synchronize()
-        _bf16_close(out, ref, f"flash two launches bounded={bound is not None}", rel=1.5e-2, max_ulp_frac=4.0)
-        assert torch.equal(out, one)        # a row's arithmetic does not depend on the workgroup shape
-
-
 def test_flash_attention_variants_agree_full_size_head(cuda, hip_lib):
     """One head at the BASELINE sequence length (S = 15 076: 58 full query blocks + a ragged one, 236 KV tiles with a
-    ragged last tile): every kernel variant and both soft-max paths against the fp32 reference."""
+    ragged last tile): both paths against the fp32 reference."""
     from aether_amd import ops
-    qb, kb, vt, ref, kmax2 = _attn_case(1, 1, 15076, 77)
+    qb, kb, vt, ref = _attn_case(1, 1, 15076, 77)
     for flags in ATTN_FLAGS:
-        for bound in (None, kmax2.to(cuda)):
-            out = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags, kmax2=bound)
-            torch.cuda.synchronize()
-            _bf16_close(out, ref, f"flash S=15076 flags={flags} bounded={bound is not None}", rel=1.5e-2, max_ulp_frac=4.0)
+        out = ops.flash_attn_fwd(qb.to(cuda), kb.to(cuda), vt.to(cuda), flags=flags)
+        torch.cuda.synchronize()
+        _bf16_close(out, ref, f"flash S=15076 flags={flags}", rel=1.5e-2, max_ulp_frac=4.0)
 
 
 @pytest.mark.parametrize("nb", [1, 2])
@@ -521,7 +468,7 @@ def test_dpm_step_fused_is_bit_identical(cuda, hip_lib, nb, steps):
 
 
 @pytest.mark.parametrize("B,H,S,n_text,K", [(1, 8, 700, 226, 512), (2, 4, 333, 20, 256), (1, 4, 1000, 0, 128)])
-@pytest.mark.parametrize("flags", [5, 4])
+@pytest.mark.parametrize("flags", [1, 0])
 def test_gemm_qkv_prep_matches_the_two_pass_path(cuda, hip_lib, B, H, S, n_text, K, flags):
     """aether_gemm_qkv_prep = the qkv projection with q/k LayerNorm(64) + RoPE + scale and the V transpose in its epilogue, against
     aether_gemm_bf16 followed by aether_qk_norm_rope.  V^T involves no arithmetic beyond the projection's rounding: bit-identical.  q / k

@@ -50,7 +50,7 @@ def test_missing_weight_is_reported():
     from aether_amd import _lib
     L = _lib.load()
     cfg = _lib.AetherVaeConfig(in_channels=3, out_channels=3, latent_channels=16, layers_per_block=3, num_levels=4, norm_num_groups=32,
-                               temporal_compression_ratio=4, sample_height=480, sample_width=720, norm_eps=1e-6, tap_reuse_max_waste=1.06, flags=5)
+                               temporal_compression_ratio=4, sample_height=480, sample_width=720, norm_eps=1e-6, tap_reuse_max_waste=1.06, flags=1)
     h = L.aether_vae_create(C.byref(cfg))
     assert L.aether_vae_workspace_bytes(h, 0, 41, 480, 720, 1) == 0
     assert b"convolution not registered: encoder.conv_" in L.aether_last_error()

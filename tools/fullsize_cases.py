@@ -38,6 +38,9 @@ if os.environ.get("AETHER_FULLSIZE_DRYRUN"):
     VAE_KW = dict(block_out_channels=(64, 128, 128, 128), layers_per_block=1, sample_height=HEIGHT, sample_width=WIDTH)
     GOLDEN_DIR = os.environ["AETHER_FULLSIZE_DRYRUN"]
 CLIP_STEPS = 4                               # the reference's default for reconstruction (P:257-261)
+GUIDED_STEPS = 2                             # guided steps of the prediction / planning fixtures (2 x B = 2 = four 42-block forwards)
+GUIDED_SEED = 42
+TRAJ_STEPS = 10                              # the longer reconstruction trajectory (drift against the step count: 4 -> 10)
 DEC_STRIDE = 8                               # decoded pixels kept in the fixture: every 8th row / column, all frames
 
 
@@ -126,3 +129,46 @@ def psnr(a: torch.Tensor, b: torch.Tensor) -> float:
     import math
     mse = ((a.double() - b.double()) ** 2).mean().item()
     return 10 * math.log10(1.0 / max(mse, 1e-20))
+
+
+# ---- BASELINE configs[2] / configs[3]: the NAMED inputs (car.png + a forward-right raymap; 01_obs.png / 01_goal.png) -----------------
+NAMED_INPUTS = os.path.join(ROOT, "tests", "golden", "named_inputs.npz")     # written by tools/make_named_inputs.py from /root/reference/assets
+
+
+def named_image(name: str):
+    """PIL image of one of the reference's example observations ('car', 'obs01', 'goal01'; 480 x 720 RGB)."""
+    import PIL.Image
+    z = np.load(NAMED_INPUTS)
+    a = z[name]
+    if os.environ.get("AETHER_FULLSIZE_DRYRUN"):
+        a = np.ascontiguousarray(a[::5, ::3][:HEIGHT, :WIDTH])
+    return PIL.Image.fromarray(a)
+
+
+def image_as_model_input(img) -> torch.Tensor:
+    """What `preprocess_inputs` (P:476-496) hands on for a PIL image that already has the target size: [1, 3, H, W] in [-1, 1]."""
+    a = np.asarray(img.convert("RGB")).astype(np.float32) / 255.0
+    return 2.0 * torch.from_numpy(a.transpose(2, 0, 1))[None] - 1.0
+
+
+def forward_right_raymap() -> np.ndarray:
+    """[41, 6, 60, 90] float32: the README's recipe for `--raymap_action` (camera_pose_to_raymap, U:867-961) on a forward-right
+    trajectory in the first frame's camera coordinates (the reference's own assets/example_raymaps/raymap_forward_right.npy is
+    not part of the mount: .MISSING_LARGE_BLOBS): eased translation 0.6 forward (+z) and 0.3 to the right (+x), yaw to the right
+    up to 15 degrees, 60-degree horizontal field of view."""
+    from aether_amd.geometry import camera_pose_to_raymap
+    s = np.linspace(0.0, 1.0, FRAMES, dtype=np.float64)
+    ease = s * s * (3 - 2 * s)
+    yaw = np.deg2rad(15.0) * ease
+    pose = np.tile(np.eye(4, dtype=np.float32), (FRAMES, 1, 1))
+    pose[:, 0, 0], pose[:, 0, 2], pose[:, 2, 0], pose[:, 2, 2] = np.cos(yaw), np.sin(yaw), -np.sin(yaw), np.cos(yaw)
+    pose[:, 0, 3], pose[:, 2, 3] = 0.3 * ease, 0.6 * ease
+    K = np.tile(np.array([[WIDTH / 2 / np.tan(np.deg2rad(30.0)), 0, WIDTH / 2], [0, WIDTH / 2 / np.tan(np.deg2rad(30.0)), HEIGHT / 2],
+                          [0, 0, 1]], np.float32), (FRAMES, 1, 1))
+    return camera_pose_to_raymap(pose, K, H=HEIGHT, W=WIDTH)
+
+
+GUIDED_CASES = {
+    "prediction": dict(image="car", goal=None, raymap=True),        # BASELINE configs[2]
+    "planning": dict(image="obs01", goal="goal01", raymap=False),   # BASELINE configs[3]
+}

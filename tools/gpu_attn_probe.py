@@ -27,16 +27,13 @@ def main():
     q, k = (unitish() * ATTN_Q_SCALE).to(torch.bfloat16), unitish().to(torch.bfloat16)
     vt = torch.zeros(1, H, 64, Spad, dtype=torch.bfloat16, device=dev)
     vt[..., :S] = torch.randn(1, H, 64, S, generator=g, device=dev).to(torch.bfloat16)
-    n2 = torch.zeros(H, Spad, device=dev)
-    n2[:, :S] = (k.float() ** 2).sum(-1).reshape(H, S)
-    kmax2 = n2.reshape(H, Spad // 64, 64).amax(-1).contiguous()
     for _ in range(2):
-        ops.flash_attn_fwd(q, k, vt, flags=a.flags, kmax2=kmax2)
+        ops.flash_attn_fwd(q, k, vt, flags=a.flags)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(a.iters):
-        ops.flash_attn_fwd(q, k, vt, flags=a.flags, kmax2=kmax2)
+        ops.flash_attn_fwd(q, k, vt, flags=a.flags)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.iters

@@ -97,9 +97,108 @@ def stage_clip(dit):
     log("clip: wrote tests/golden/fullsize_clip.npz")
 
 
+def stage_guided(dit, task):
+    """BASELINE configs[2] / configs[3] on their NAMED inputs at the BASELINE geometry: the whole guided call (P:690-965) with
+    GUIDED_STEPS steps, dynamic classifier-free guidance (P:880-893) and a CPU generator.  Recorded: the image (/ goal) posterior and
+    its sampled latents (what `prepare_latents` builds `condition_latents` from, P:557-650), the B = 2 noise prediction of step 0
+    (unconditional, conditional: all 42 blocks at batch 2, every 2nd row / column), the per-step guidance scale, the final latents
+    (exact bf16 bits) and the decoded rgb / disparity (every 8th row / column)."""
+    from aether_amd.scheduler import CogVideoXDPMScheduler
+    from oracle.pipeline import sample
+    case = fc.GUIDED_CASES[task]
+    vae = fc.build_oracle_vae()
+    image = fc.image_as_model_input(fc.named_image(case["image"]))
+    goal = fc.image_as_model_input(fc.named_image(case["goal"])) if case["goal"] else None
+    raymap = torch.from_numpy(fc.forward_right_raymap())[None] if case["raymap"] else None
+    times, mark, step_lat = {}, [time.perf_counter()], []
+
+    def on_step(i, latents):
+        now = time.perf_counter()
+        times[f"step{i}"] = now - mark[0]
+        mark[0] = now
+        step_lat.append(latents[:, :, :, ::6, ::6].clone())
+        log(f"{task}: step {i} done ({times[f'step{i}']:.1f} s)")
+
+    trace = {"on_step": on_step}
+    t0 = time.perf_counter()
+    rgb, disp, rm = sample(task, dit, vae, CogVideoXDPMScheduler(), fc.prompt_embeds(), image=image, goal=goal, raymap=raymap,
+                           height=fc.HEIGHT, width=fc.WIDTH, num_frames=fc.FRAMES, num_inference_steps=fc.GUIDED_STEPS,
+                           generator=torch.Generator().manual_seed(fc.GUIDED_SEED), rope=fc.rope_tables(),
+                           compute_dtype=torch.float32, trace=trace)
+    total = time.perf_counter() - t0
+    log(f"{task}: whole guided call took {total:.1f} s")
+    s = fc.DEC_STRIDE
+    cond = trace["condition_latents"]                                                  # [1,11,40,60,90] bf16
+    meta = dict(seconds_cpu_total=total, step_seconds=times, threads=torch.get_num_threads(), torch=torch.__version__, task=task,
+                dit_seed=fc.DIT_SEED, vae_seed=fc.VAE_SEED, seed=fc.GUIDED_SEED, steps=fc.GUIDED_STEPS, inputs=case,
+                noise_pred_rms=[float(p.pow(2).mean().sqrt()) for p in trace["noise_pred"]],
+                noise_pred_max=[float(p.abs().max()) for p in trace["noise_pred"]],
+                condition_sum=float(cond.double().sum()), condition_abs_sum=float(cond.double().abs().sum()),
+                raymap_sum=(float(raymap.double().sum()) if raymap is not None else None))
+    arrays = dict(
+        image_posterior_mean=trace["posterior"][0][0].numpy().astype(np.float16),      # [1,16,1,60,90]
+        image_latents_bits=fc.bf16_bits(cond[:, :1, :16]),                             # sampled + scaled, exact
+        noise_pred0_s2=trace["noise_pred"][0][..., ::2, ::2].numpy().astype(np.float16),   # [2,11,56,30,45]: (uncond, cond)
+        initial_latents_sum=np.float64(trace["initial_latents"].double().sum().item()),
+        final_latents_bits=fc.bf16_bits(trace["final_latents"]),
+        step_latents_s6=np.stack([fc.bf16_bits(x) for x in step_lat]),
+        rgb_s8=rgb[:, ::s, ::s].numpy().astype(np.float16), disparity_s8=disp[:, ::s, ::s].numpy().astype(np.float16),
+        meta=json.dumps(meta))
+    if goal is not None:
+        arrays["goal_posterior_mean"] = trace["posterior"][1][0].numpy().astype(np.float16)
+        arrays["goal_latents_bits"] = fc.bf16_bits(cond[:, -1:, :16])
+    np.savez_compressed(os.path.join(fc.GOLDEN_DIR, f"fullsize_{task}.npz"), **arrays)
+    log(f"{task}: wrote tests/golden/fullsize_{task}.npz")
+
+
+def stage_traj(dit):
+    """The reconstruction call of `stage_clip` (same clip, same seed -> same posterior sample and initial latents) with TRAJ_STEPS steps
+    and no decodes: per-step latents (every 6th row / column) and the final latents (every 2nd) — how the drift against the fp32
+    oracle grows with the number of steps."""
+    from aether_amd.scheduler import CogVideoXDPMScheduler
+    from oracle.pipeline import sample
+
+    class NoDecode:
+        """The decodes of P:931,936 are irrelevant to the latent trajectory: replace them by zeros of the right shape."""
+        def __init__(self, vae):
+            self.vae, self.config = vae, vae.config
+
+        def encode(self, x):
+            return self.vae.encode(x)
+
+        def decode(self, z):
+            import types
+            return types.SimpleNamespace(sample=torch.zeros(z.shape[0], 3, (z.shape[2] - 1) * 4 + 1, z.shape[3] * 8, z.shape[4] * 8, dtype=z.dtype))
+
+    vae = NoDecode(fc.build_oracle_vae())
+    v = fc.video_as_model_input(fc.clip_video())
+    step_lat, times, mark = [], {}, [time.perf_counter()]
+
+    def on_step(i, latents):
+        now = time.perf_counter()
+        times[f"step{i}"] = now - mark[0]
+        mark[0] = now
+        step_lat.append(latents[:, :, :, ::6, ::6].clone())
+        log(f"traj: step {i} done ({times[f'step{i}']:.1f} s)")
+
+    trace = {"on_step": on_step}
+    t0 = time.perf_counter()
+    sample("reconstruction", dit, vae, CogVideoXDPMScheduler(), fc.prompt_embeds(), video=v, height=fc.HEIGHT, width=fc.WIDTH,
+           num_frames=fc.FRAMES, num_inference_steps=fc.TRAJ_STEPS, generator=torch.Generator().manual_seed(fc.CLIP_SEED),
+           rope=fc.rope_tables(), compute_dtype=torch.float32, trace=trace)
+    total = time.perf_counter() - t0
+    meta = dict(seconds_cpu_total=total, step_seconds=times, threads=torch.get_num_threads(), torch=torch.__version__, steps=fc.TRAJ_STEPS,
+                dit_seed=fc.DIT_SEED, vae_seed=fc.VAE_SEED, clip_seed=fc.CLIP_SEED,
+                noise_pred_rms=[float(p.pow(2).mean().sqrt()) for p in trace["noise_pred"]])
+    np.savez_compressed(os.path.join(fc.GOLDEN_DIR, "fullsize_traj.npz"),
+                        step_latents_s6=np.stack([fc.bf16_bits(x) for x in step_lat]),
+                        final_latents_s2_bits=fc.bf16_bits(trace["final_latents"][..., ::2, ::2]), meta=json.dumps(meta))
+    log(f"traj: {fc.TRAJ_STEPS}-step reconstruction trajectory took {total:.1f} s; wrote tests/golden/fullsize_traj.npz")
+
+
 def main():
     stages = sys.argv[1:] or ["dit", "clip"]
-    torch.set_num_threads(os.cpu_count() or 8)
+    torch.set_num_threads(int(os.environ.get("AETHER_GOLDEN_THREADS", os.cpu_count() or 8)))
     log(f"building the 42-block oracle transformer (seed {fc.DIT_SEED}) ...")
     t0 = time.perf_counter()
     dit, _ = fc.build_oracle_dit()
@@ -108,6 +207,11 @@ def main():
         stage_dit(dit)
     if "clip" in stages:
         stage_clip(dit)
+    for task in ("prediction", "planning"):
+        if task in stages:
+            stage_guided(dit, task)
+    if "traj" in stages:
+        stage_traj(dit)
 
 
 if __name__ == "__main__":

@@ -96,6 +96,23 @@ def camera_pose_to_raymap(camera_pose: np.ndarray, intrinsic: np.ndarray, ray_o_
     return np.concatenate([d.astype(np.float32), o], axis=1)
 
 
+def forward_right_raymap(frames: int = 41, height: int = 480, width: int = 720, forward: float = 0.6, right: float = 0.3, yaw_deg: float = 15.0,
+                         fov_x_deg: float = 60.0) -> np.ndarray:
+    """A `--raymap_action` input made the way the reference's README prescribes ("Inference with your own raymap action": camera poses in the
+    first frame's camera coordinates -> `camera_pose_to_raymap`, U:867-961): eased translation `forward` along +z and `right` along +x with a
+    yaw to the right, pinhole intrinsics from the horizontal field of view.  Stands in for assets/example_raymaps/raymap_forward_right.npy,
+    which the reference repository keeps as a large blob.  Returns [frames, 6, height/8, width/8] float32."""
+    s = np.linspace(0.0, 1.0, frames, dtype=np.float64)
+    ease = s * s * (3 - 2 * s)
+    yaw = np.deg2rad(yaw_deg) * ease
+    pose = np.tile(np.eye(4, dtype=np.float32), (frames, 1, 1))
+    pose[:, 0, 0], pose[:, 0, 2], pose[:, 2, 0], pose[:, 2, 2] = np.cos(yaw), np.sin(yaw), -np.sin(yaw), np.cos(yaw)
+    pose[:, 0, 3], pose[:, 2, 3] = right * ease, forward * ease
+    f = width / 2 / np.tan(np.deg2rad(fov_x_deg / 2))
+    K = np.tile(np.array([[f, 0, width / 2], [0, f, height / 2], [0, 0, 1]], np.float32), (frames, 1, 1))
+    return camera_pose_to_raymap(pose, K, H=height, W=width)
+
+
 def raymap_to_poses(raymap: np.ndarray, camera_pose: Optional[np.ndarray] = None, ray_o_scale_inv: float = 1.0,
                     return_intrinsics: bool = True):
     """U:219-280.  raymap [T,6,h,w]: channels 0-2 ray directions, 3-5 signed-log1p ray origins.  Returns

@@ -501,7 +501,8 @@ class AetherV1PipelineCogVideoX(_PipelineBase):
         # the element-wise tail of a step as one HIP kernel: this repo's DPM scheduler, v-prediction, bf16 latents on an MI355X, and a
         # guidance scale that is not a per-sample tensor; anything else takes the reference's PyTorch sequence
         fused_tail = (self.fuse_step_tail and dpm and hasattr(self.scheduler, "step_fused") and latents.is_cuda and latents.dtype == torch.bfloat16
-                      and getattr(self.scheduler.config, "prediction_type", None) == "v_prediction" and latents.shape[0] == 1)
+                      and getattr(self.scheduler.config, "prediction_type", None) == "v_prediction" and latents.shape[0] == 1
+                      and latents.numel() % 8 == 0)            # the kernel moves 16-byte pieces; other sizes take the PyTorch sequence
 
         with self.progress_bar(total=num_inference_steps) as bar:
             old_x0 = None
@@ -550,7 +551,16 @@ class AetherV1PipelineCogVideoX(_PipelineBase):
         elif self.decode_concurrently and hasattr(self.vae, "decode_pair") and latents.is_cuda:
             # the two decodes of P:931,936 on two HIP streams (aether_amd.vae.AetherVAE.decode_pair): same kernels, bit-identical results
             inv = 1 / self.vae_scaling_factor_image
-            rgb_decoded, disparity_decoded = self.vae.decode_pair(inv * rgb_latents.permute(0, 2, 1, 3, 4), inv * disparity_latents.permute(0, 2, 1, 3, 4))
+            try:
+                rgb_decoded, disparity_decoded = self.vae.decode_pair(inv * rgb_latents.permute(0, 2, 1, 3, 4), inv * disparity_latents.permute(0, 2, 1, 3, 4))
+            except torch.OutOfMemoryError:
+                # the second decode context needs a workspace of its own: without room for it the two decodes run one after the other
+                # (the reference's order), and the pair is not tried again on this pipeline
+                self.decode_concurrently = False
+                if hasattr(self.vae, "_twin"):
+                    self.vae._twin = None
+                torch.cuda.empty_cache()
+                rgb_decoded, disparity_decoded = self.decode_latents(rgb_latents), self.decode_latents(disparity_latents)
         else:
             rgb_decoded, disparity_decoded = self.decode_latents(rgb_latents), self.decode_latents(disparity_latents)
         disparity_video = disparity_decoded.mean(dim=1, keepdim=False)

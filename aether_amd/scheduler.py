@@ -114,7 +114,7 @@ class CogVideoXDPMScheduler:
         return ((a / (1 - a)) ** 0.5).log()
 
     def _coefficients(self, timestep, timestep_back, second_order_possible: bool):
-        """The float64 host scalars of one update (same expressions, same order as `step`)."""
+        """The float64 host scalars of one update (diffusers' `step` expressions, in its order) — used by `step` and `step_fused` alike."""
         c = self.config
         t = int(timestep)
         prev_t = t - c.num_train_timesteps // self.num_inference_steps
@@ -166,32 +166,20 @@ class CogVideoXDPMScheduler:
         if self.num_inference_steps is None:
             raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
         c = self.config
-        t = int(timestep)
-        prev_t = t - c.num_train_timesteps // self.num_inference_steps
-        a_t = self.alphas_cumprod[t]
-        a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
-        a_back = self.alphas_cumprod[int(timestep_back)] if timestep_back is not None else None
-        beta_t = 1 - a_t
+        k = self._coefficients(timestep, timestep_back, old_pred_original_sample is not None)     # the ONE place the schedule scalars come from
         if c.prediction_type == "epsilon":
-            x0 = (sample - beta_t ** 0.5 * model_output) / a_t ** 0.5
+            x0 = (sample - k["b_sqrt"] * model_output) / k["a_sqrt"]
         elif c.prediction_type == "sample":
             x0 = model_output
         elif c.prediction_type == "v_prediction":
-            x0 = (a_t ** 0.5) * sample - (beta_t ** 0.5) * model_output
+            x0 = k["a_sqrt"] * sample - k["b_sqrt"] * model_output
         else:
             raise ValueError(f"prediction_type given as {c.prediction_type} must be one of `epsilon`, `sample`, or `v_prediction`")
-        lamb, lamb_next = self._lambda(a_t), self._lambda(a_prev)
-        h = lamb_next - lamb
-        m1 = ((1 - a_prev) / (1 - a_t)) ** 0.5 * (-h).exp()
-        m2 = (-2 * h).expm1() * a_prev ** 0.5
-        m_noise = (1 - a_prev) ** 0.5 * (1 - (-2 * h).exp()) ** 0.5
         noise = randn_tensor(sample.shape, generator=generator, device=sample.device, dtype=sample.dtype)
-        prev_sample = m1 * sample - m2 * x0 + m_noise * noise
-        if old_pred_original_sample is None or prev_t < 0:
+        prev_sample = k["m1"] * sample - k["m2"] * x0 + k["m_noise"] * noise
+        if not k["second"]:
             return (prev_sample, x0)
-        r = (lamb - self._lambda(a_back)) / h
-        m3, m4 = 1 + 1 / (2 * r), 1 / (2 * r)
-        d = m3 * x0 - m4 * old_pred_original_sample
+        d = k["m3"] * x0 - k["m4"] * old_pred_original_sample
         noise = randn_tensor(sample.shape, generator=generator, device=sample.device, dtype=sample.dtype)
-        prev_sample = m1 * sample - m2 * d + m_noise * noise
+        prev_sample = k["m1"] * sample - k["m2"] * d + k["m_noise"] * noise
         return (prev_sample, x0)

@@ -183,8 +183,6 @@ class AetherVAE:
         self._tap_reuse_max_waste = float(value)
         if getattr(self, "_loaded", False):
             self._register_c_plan()
-            if getattr(self, "_twin", None) is not None:
-                self._twin = None
 
     def enable_tiling(self):
         self.use_tiling = True
@@ -248,6 +246,7 @@ class AetherVAE:
         self._handle = h
         self._workspace = None
         self._graphs.clear()
+        self._twin = None          # a twin context (decode_pair) holds the previous handle's weight pointers: rebuilt on the next pair
 
         def conv(name, cv: _Conv):
             kt, kh, kw = cv.ksize if len(cv.ksize) == 3 else ((1,) + tuple(cv.ksize) if len(cv.ksize) == 2 else (1, 1, 1))
@@ -736,7 +735,10 @@ class AetherVAE:
             # queue of the caller's stream (4 hardware queues, assigned round robin) — and two graphs on one queue do not overlap at all
             # (measured: the same pair 0.74 s in one process, 0.81 s = sequential in another, depending on how many streams existed before)
             self._side_stream = torch.cuda.Stream(device=self.device, priority=-1)
-        self._twin.use_tiling, self._twin.use_slicing, self._twin.use_graphs = self.use_tiling, self.use_slicing, self.use_graphs
+        if self._twin._flags != self._flags:          # the flags are baked into the C handle: a changed value needs a new twin
+            self._twin = self._make_twin()
+        for k in ("use_tiling", "use_slicing", "use_graphs", "use_c_plan"):
+            setattr(self._twin, k, getattr(self, k))
         cur = torch.cuda.current_stream(self.device)
         self._side_stream.wait_stream(cur)
         with torch.cuda.stream(self._side_stream):

@@ -122,8 +122,110 @@ def run_windows(call_window: Callable[[int], "object"], starts: Sequence[int], g
     return results
 
 
+def run_windows_merged(call_window: Callable[[int], "object"], starts: Sequence[int], *, height: int, width: int,
+                       gather_device: Optional[torch.device] = None, smooth_camera: bool = True, smooth_method: str = "kalman",
+                       out_dtype=np.float64, pinned: bool = False, force_collective: bool = False, timings: Optional[dict] = None):
+    """Windows + exchange + merge as ONE pipeline (what scripts/demo.py and bench.py run for a long clip): the windows are processed in ROUNDS of
+    one window per rank (window w on rank w mod N, as in `run_windows`); after each round ONE `dist.gather(dst=0)` moves that round's outputs
+    (232 MB fp32 per window at 41 x 480 x 720, packed on the device) to rank 0, which merges them into the running result (WindowMerger: the
+    blend is sequential in the window index, and round j holds exactly the next N windows) on a side stream WHILE every rank — rank 0 included —
+    computes its window of round j + 1.  After the last round only that round's merge, the back-projection and the D2H copy remain (with one
+    gather at the very end, as `run_windows` + `blend_and_merge_window_results` do, the whole merge is a serial tail on rank 0).
+    Returns (rgb, disparity, poses, pointmaps) on rank 0 and None elsewhere; values are those of `blend_and_merge_window_results(run_windows(...),
+    device=...)` bit for bit (same kernels, same order).  `timings` (a dict) receives 'windows_and_gather' and 'merge_tail' in seconds."""
+    import time
+    dist = _dist()
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
+    collective = dist is not None and (world > 1 or force_collective)
+    nccl = collective and dist.get_backend() == "nccl"
+    if gather_device is not None:
+        dev = torch.device(gather_device)
+    else:
+        dev = torch.device("cuda", torch.cuda.current_device()) if (nccl or (not collective and torch.cuda.is_available())) else torch.device("cpu")
+    if collective and not nccl:
+        dev = torch.device("cpu")
+    on_gpu = dev.type == "cuda"
+    side = torch.cuda.Stream(device=dev) if on_gpu else None
+    merger, shapes, sizes = None, None, None
+    n_rounds = (len(starts) + world - 1) // world
+    t_begin = time.perf_counter()
+
+    def merge(idx, rgb, disp, ray):
+        nonlocal merger
+        if merger is None:
+            merger = WindowMerger(total_frames=starts[-1] + rgb.shape[0], window_frames=rgb.shape[0], frame_hw=tuple(disp.shape[1:]), height=height, width=width,
+                                  device=dev, smooth_camera=smooth_camera, smooth_method=smooth_method, out_dtype=out_dtype, pinned=pinned)
+        merger.add(WindowResult(starts[idx], rgb, disp, ray.cpu().numpy().copy()))
+
+    for j in range(n_rounds):
+        idx = j * world + rank
+        out = call_window(starts[idx]) if idx < len(starts) else None
+        parts = None if out is None else [_as_tensor(out.rgb), _as_tensor(out.disparity), _as_tensor(out.raymap)]
+        if not collective:
+            a, b, c = (t.to(dev) for t in parts)
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    merge(idx, a, b, c)
+                for t in (a, b, c):
+                    t.record_stream(side)
+            else:
+                merge(idx, a, b, c)
+            continue
+        if shapes is None:                                   # every rank has a window in round 0 unless there are fewer windows than ranks
+            mine = tuple(tuple(t.shape) for t in parts) if parts is not None else None
+            every = [None] * world
+            dist.all_gather_object(every, mine)
+            shapes = next(x for x in every if x is not None)
+            sizes = [int(np.prod(x)) for x in shapes]
+        payload = torch.empty(sum(sizes) + 1, dtype=torch.float32, device=dev)      # last element: 1 = slot holds a window
+        if parts is not None:
+            torch.cat([t.reshape(-1).to(dev, torch.float32) for t in parts] + [torch.ones(1, dtype=torch.float32, device=dev)], out=payload)
+        else:
+            payload.zero_()
+        gathered = [torch.empty_like(payload) for _ in range(world)] if rank == 0 else None
+        work = dist.gather(payload, gathered, dst=0, async_op=True)
+        if rank != 0:
+            work.wait()
+            continue
+
+        def merge_round(j=j, gathered=gathered, work=work):
+            work.wait()                                      # stream-level under nccl: the merge kernels queue behind the gather
+            for r, g in enumerate(gathered):
+                i = j * world + r
+                if i >= len(starts):
+                    continue
+                a, b, c, flag = torch.split(g, sizes + [1])
+                merge(i, a.view(shapes[0]), b.view(shapes[1]), c.view(shapes[2]))
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                merge_round()
+            for g in gathered:
+                g.record_stream(side)
+        else:
+            merge_round()
+    if dist is not None and collective:
+        pass
+    if rank != 0:
+        if timings is not None:
+            timings["windows_and_gather"] = time.perf_counter() - t_begin
+        return None
+    if side is not None:
+        torch.cuda.current_stream(dev).synchronize()         # this rank's last window is done (the merges of earlier rounds ran beside it)
+    t_mid = time.perf_counter()
+    if side is not None:
+        torch.cuda.current_stream(dev).wait_stream(side)
+    merged = merger.finish()
+    if timings is not None:
+        timings["windows_and_gather"] = t_mid - t_begin
+        timings["merge_tail"] = time.perf_counter() - t_mid
+    return merged
+
+
 def blend_and_merge_window_results(results: Sequence[WindowResult], *, height: int, width: int, align_pointmaps: bool = False,
-                                   smooth_camera: bool = True, smooth_method: str = "kalman", device: Optional[torch.device] = None):
+                                   smooth_camera: bool = True, smooth_method: str = "kalman", device: Optional[torch.device] = None,
+                                   out_dtype=np.float64, pinned: bool = False):
     """The reference's sequential merge of overlapping windows (D:254-422), on the host in float64 like the reference:
     window k is brought into the frame of everything merged so far — disparity by a least-squares scale over the overlap
     (pixels with disparity > 0.1), camera poses by a similarity fitted on the overlapping cameras, focal lengths by their mean
@@ -132,12 +234,13 @@ def blend_and_merge_window_results(results: Sequence[WindowResult], *, height: i
     Reference quirks kept on purpose: windows' raymaps are decoded in place (geometry.raymap_to_poses); the aligned poses of
     windows k >= 1 carry the similarity's scale in element [3,3] outside the overlap (apply_transformation on 4x4 inputs).
     `device`: run the per-pixel part (scale fit, cross-fades, back-projection: SURVEY.md §8f-2) as float64 torch operations on
-    that device instead of numpy on the host (`_merge_on_device`); the ≤ 41-pose camera algebra stays on the host either way."""
+    that device instead of numpy on the host (`WindowMerger`); the ≤ 41-pose camera algebra stays on the host either way.  `out_dtype` /
+    `pinned` (device path only): see WindowMerger."""
     from . import geometry as G
 
     if device is not None and not align_pointmaps:
         return _merge_on_device(results, height=height, width=width, smooth_camera=smooth_camera, smooth_method=smooth_method,
-                                device=torch.device(device))
+                                device=torch.device(device), out_dtype=out_dtype, pinned=pinned)
     sm = smooth_method if smooth_camera else "none"
     first = results[0]
     n_win = first.rgb.shape[0]
@@ -207,72 +310,99 @@ def blend_and_merge_window_results(results: Sequence[WindowResult], *, height: i
     return rgb, disp, poses, pointmaps
 
 
-def _merge_on_device(results: Sequence[WindowResult], *, height: int, width: int, smooth_camera: bool, smooth_method: str,
-                     device: torch.device):
-    """The per-pixel work of blend_and_merge_window_results (align_pointmaps=False) on `device`: same operations, dtypes and
-    order as the host path (float32 operands of the scale fit, float64 everything else).  On an MI355X the three passes are HIP
-    kernels of libaether_hip.so (csrc/merge_kernels.hip: masked scale-fit reduction, fused scale + cross-fade of disparity and
-    colour, back-projection) reading the gathered fp32 window outputs where `run_windows` left them; on any other device the same
-    arithmetic runs as torch operations (CPU tests).  One deliberate difference: the HIP scale fit accumulates Σ m·p·t and Σ m·p² in
-    float64 and divides in float64 before rounding the scale to float32, where the reference (compute_scale, U:847-864) sums and
-    divides in float32 — the kernel's value is the more accurate one and differs from the float32 result by ~1e-7 relative (the
-    tests' tolerance against the reference's own outputs, tests/golden/blend.npz, is 1e-5).
-    A 192-frame clip (8 windows) costs the host about 21 s of float64 numpy.
-    One D2H copy of the merged arrays at the end."""
-    from . import geometry as G
+_PINNED: dict = {}
 
-    sm = smooth_method if smooth_camera else "none"
-    first = results[0]
-    n_win = first.rgb.shape[0]
-    H, W = first.disparity.shape[1:]
-    total = results[-1].start + results[-1].rgb.shape[0]
-    f64 = dict(dtype=torch.float64, device=device)
-    native = device.type == "cuda"
-    if native:
-        from . import _lib
-        lib = _lib.load()
-        stream = torch.cuda.current_stream(device).cuda_stream
-        scratch = torch.empty(4096 + 3, **f64)
-    up = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))).to(device)  # noqa: E731
-    up32 = lambda a: up(a).to(torch.float32).contiguous()  # noqa: E731
-    rgb = torch.empty((total, H, W, 3), **f64)
-    disp = torch.empty((total, H, W), **f64)
-    poses = np.empty((total, 4, 4))
-    focals = np.empty((total,))
 
-    def write_window(r_rgb, r_disp, t0, ov, fade_h, scale_dev):
+def _pinned(tag: str, shape, dtype) -> torch.Tensor:
+    """Page-locked host buffers for the merged arrays, allocated once per (shape, dtype) and reused by later merges: a D2H copy into pageable
+    memory runs at ~7 GB/s on this box (0.5 s for the 3.7 GB a 192-frame clip's float64 arrays), into pinned memory at PCIe speed."""
+    key = (tag, tuple(shape), dtype)         # rgb and the point maps have the same shape: one buffer per ROLE
+    if key not in _PINNED:
+        _PINNED[key] = torch.empty(shape, dtype=dtype, pin_memory=True)
+    return _PINNED[key]
+
+
+class WindowMerger:
+    """The per-pixel work of blend_and_merge_window_results (align_pointmaps=False) on `device`, INCREMENTALLY: `add(result)` merges the next
+    window (windows must arrive in start order — the blend is sequential in the window index: D:269-401), `finish()` back-projects and copies
+    the merged arrays to the host.  Same operations, dtypes and order as the host path (float32 operands of the scale fit, float64 everything
+    else).  On an MI355X the three passes are HIP kernels of libaether_hip.so (csrc/merge_kernels.hip: masked scale-fit reduction, fused
+    scale + cross-fade of disparity and colour, back-projection) reading the gathered fp32 window outputs where `run_windows` left them; on any
+    other device the same arithmetic runs as torch operations (CPU tests).  One deliberate difference: the HIP scale fit accumulates Σ m·p·t
+    and Σ m·p² in float64 and divides in float64 before rounding the scale to float32, where the reference (compute_scale, U:847-864) sums and
+    divides in float32 — the kernel's value is the more accurate one and differs from the float32 result by ~1e-7 relative (the tests'
+    tolerance against the reference's own outputs, tests/golden/blend.npz, is 1e-5).
+    `out_dtype`: dtype of the returned rgb / disparity / pointmap arrays — float64 like the reference's (np.ones defaults, D:262-268) unless
+    the caller asks for float32 (half the D2H bytes; scripts/demo.py does unless --float64_outputs: everything it writes is uint8 / float32).
+    `pinned`: copy into reusable page-locked buffers (the returned arrays are views of them: valid until the next merge of the same shape)."""
+
+    def __init__(self, *, total_frames: int, window_frames: int, frame_hw, height: int, width: int, device, smooth_camera: bool = True,
+                 smooth_method: str = "kalman", out_dtype=np.float64, pinned: bool = False):
+        self.device = torch.device(device)
+        self.total, self.n_win, (self.H, self.W) = int(total_frames), int(window_frames), frame_hw
+        self.height, self.width = height, width
+        self.smooth_camera, self.sm = smooth_camera, (smooth_method if smooth_camera else "none")
+        self.out_dtype, self.pinned = np.dtype(out_dtype), pinned
+        self.native = self.device.type == "cuda"
+        f64 = dict(dtype=torch.float64, device=self.device)
+        if self.native:
+            from . import _lib
+            self._lib, self.lib = _lib, _lib.load()
+            self.scratch = torch.empty(4096 + 3, **f64)
+        self.rgb = torch.empty((self.total, self.H, self.W, 3), **f64)
+        self.disp = torch.empty((self.total, self.H, self.W), **f64)
+        self.poses = np.empty((self.total, 4, 4))
+        self.focals = np.empty((self.total,))
+        self.end, self.prev_start, self.count = 0, None, 0
+
+    def _up(self, a):
+        return (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))).to(self.device)
+
+    def _up32(self, a):
+        return self._up(a).to(torch.float32).contiguous()
+
+    def _write_window(self, r_rgb, r_disp, t0, ov, fade_h, scale_dev):
         """frames [t0, t0 + n) of the merged arrays from one window (cross-fade over the first `ov`)."""
         n = r_rgb.shape[0]
         fade_c = (C.c_double * max(ov, 1))(*fade_h) if ov else None
-        _lib.check(lib.aether_merge_window(r_rgb.data_ptr(), r_disp.data_ptr(), rgb[t0].data_ptr(), disp[t0].data_ptr(), n, ov, H * W, fade_c,
-                                           None if scale_dev is None else scale_dev.data_ptr(), stream), "aether_merge_window")
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._lib.check(self.lib.aether_merge_window(r_rgb.data_ptr(), r_disp.data_ptr(), self.rgb[t0].data_ptr(), self.disp[t0].data_ptr(), n, ov,
+                                                     self.H * self.W, fade_c, None if scale_dev is None else scale_dev.data_ptr(), stream),
+                        "aether_merge_window")
 
-    if native:
-        write_window(up32(first.rgb), up32(first.disparity), 0, 0, [], None)
-    else:
-        rgb[:n_win], disp[:n_win] = up(first.rgb), up(first.disparity)
-    pm0 = G.postprocess_pointmap(_host(first.disparity), first.raymap, vae_downsample_scale=8, ray_o_scale_inv=0.1,
-                                 smooth_camera=smooth_camera, smooth_method=sm, with_pointmap=False)
-    poses[:n_win] = pm0["camera_pose"]
-    focals[:n_win] = (pm0["intrinsics"][:, 0, 0] + pm0["intrinsics"][:, 1, 1]) / 2
-    end = n_win
-    for k in range(1, len(results)):
-        r, t0 = results[k], results[k].start
+    def add(self, r: "WindowResult") -> None:
+        from . import geometry as G
+        H, W, n_win, device = self.H, self.W, self.n_win, self.device
+        rgb, disp, poses, focals = self.rgb, self.disp, self.poses, self.focals
+        if self.count == 0:
+            assert r.start == 0
+            if self.native:
+                self._write_window(self._up32(r.rgb), self._up32(r.disparity), 0, 0, [], None)
+            else:
+                rgb[:n_win], disp[:n_win] = self._up(r.rgb), self._up(r.disparity)
+            pm0 = G.postprocess_pointmap(_host(r.disparity), r.raymap, vae_downsample_scale=8, ray_o_scale_inv=0.1,
+                                         smooth_camera=self.smooth_camera, smooth_method=self.sm, with_pointmap=False)
+            poses[:n_win] = pm0["camera_pose"]
+            focals[:n_win] = (pm0["intrinsics"][:, 0, 0] + pm0["intrinsics"][:, 1, 1]) / 2
+            self.end, self.prev_start, self.count = n_win, 0, 1
+            return
+        t0, end = r.start, self.end
         t1 = t0 + r.rgb.shape[0]
-        ov = results[k - 1].start + n_win - t0
+        ov = self.prev_start + n_win - t0
         assert end == t0 + ov
         fade_h = np.linspace(1, 0, ov)
         # the HIP merge kernels take 1..64 overlapping frames; windows that do not overlap (the reference's compute_scale then returns
         # 0, U:847-864) or overlap by more run the same arithmetic as torch operations on the device
-        if native and 0 < ov <= 64:
-            r_disp, r_rgb = up32(r.disparity), up32(r.rgb)
+        if self.native and 0 < ov <= 64:
+            r_disp, r_rgb = self._up32(r.disparity), self._up32(r.rgb)
+            stream = torch.cuda.current_stream(device).cuda_stream
             # scale fit (U:847-864) -> device scalar, then ONE pass: scale, cross-fade of disparity and colour, tail frames
-            _lib.check(lib.aether_merge_scale_fit(r_disp.data_ptr(), disp[t0].data_ptr(), ov * H * W, scratch.data_ptr(), 4096,
-                                                  scratch[4096:].data_ptr(), stream), "aether_merge_scale_fit")
-            write_window(r_rgb, r_disp, t0, ov, fade_h.tolist(), scratch[4098:])
+            self._lib.check(self.lib.aether_merge_scale_fit(r_disp.data_ptr(), disp[t0].data_ptr(), ov * H * W, self.scratch.data_ptr(), 4096,
+                                                            self.scratch[4096:].data_ptr(), stream), "aether_merge_scale_fit")
+            self._write_window(r_rgb, r_disp, t0, ov, fade_h.tolist(), self.scratch[4098:])
         else:
             fade = torch.from_numpy(fade_h).to(device)
-            r_disp, r_rgb = up(r.disparity), up(r.rgb)
+            r_disp, r_rgb = self._up(r.disparity), self._up(r.rgb)
             # scale fit: float32 operands and float32 sums like the reference's torch code (U:847-864)
             p, t = r_disp[:ov].float(), disp[t0:end].float()
             m = (p > 0.1).float()
@@ -294,29 +424,67 @@ def _merge_on_device(results: Sequence[WindowResult], *, height: int, width: int
         w_focals = (focals[t0:end] / w_focals[:ov]).mean() * w_focals
         focals[t0:end] = focals[t0:end] * fade_h + w_focals[:ov] * (1 - fade_h)
         focals[end:t1] = w_focals[ov:]
-        end = t1
+        self.end, self.prev_start, self.count = t1, t0, self.count + 1
 
-    # back-projection (U:393-403): world = pose[:3,:4] · [K⁻¹ · (u+.5, v+.5, 1) · depth ; 1], pixel grid in float32 like the reference
-    K = np.zeros((total, 3, 3))
-    K[:, 0, 0] = K[:, 1, 1] = focals
-    K[:, 0, 2], K[:, 1, 2], K[:, 2, 2] = 0.5 * width, 0.5 * height, 1.0
-    K_inv = torch.from_numpy(np.linalg.inv(K)).to(device)
-    P = torch.from_numpy(poses[:, :3, :4].copy()).to(device)
-    pointmaps = torch.empty((total, H, W, 3), **f64)
-    if native:
-        _lib.check(lib.aether_backproject(disp.data_ptr(), K_inv.contiguous().data_ptr(), P.contiguous().data_ptr(), pointmaps.data_ptr(),
-                                          total, H, W, stream), "aether_backproject")
-    else:
-        v, u = torch.meshgrid(torch.arange(H, device=device), torch.arange(W, device=device), indexing="ij")
-        pix = torch.stack([u.reshape(-1) + 0.5, v.reshape(-1) + 0.5, torch.ones(H * W, device=device)], 0).float().double()   # [3, HW]
-        step = 16
-        for i in range(0, total, step):
-            j = min(i + step, total)
-            depth = (1 / disp[i:j].clamp(1e-8, 1e8)).reshape(j - i, 1, H * W)
-            cam = (K_inv[i:j] @ pix) * depth                                                         # [n, 3, HW]
-            world = P[i:j, :, :3] @ cam + P[i:j, :, 3:]                                               # [n, 3, HW]
-            pointmaps[i:j] = world.transpose(1, 2).reshape(j - i, H, W, 3)
-    return rgb.cpu().numpy(), disp.cpu().numpy(), poses, pointmaps.cpu().numpy()
+    def finish(self):
+        """Back-projection (U:393-403): world = pose[:3,:4] · [K⁻¹ · (u+.5, v+.5, 1) · depth ; 1], pixel grid in float32 like the reference; then
+        the D2H copies (rgb and disparity leave on a copy stream while the back-projection kernel runs)."""
+        assert self.end == self.total, "windows missing"
+        device, total, H, W = self.device, self.total, self.H, self.W
+        K = np.zeros((total, 3, 3))
+        K[:, 0, 0] = K[:, 1, 1] = self.focals
+        K[:, 0, 2], K[:, 1, 2], K[:, 2, 2] = 0.5 * self.width, 0.5 * self.height, 1.0
+        K_inv = torch.from_numpy(np.linalg.inv(K)).to(device)
+        P = torch.from_numpy(self.poses[:, :3, :4].copy()).to(device)
+        tdt = torch.float64 if self.out_dtype == np.float64 else torch.float32
+
+        def to_host(tag, t, copy_stream=None):
+            t = t if t.dtype == tdt else t.to(tdt)
+            if not (self.native and self.pinned):
+                return t.cpu()
+            dst = _pinned(tag, t.shape, tdt)
+            if copy_stream is None:
+                dst.copy_(t, non_blocking=True)
+            else:
+                copy_stream.wait_stream(torch.cuda.current_stream(device))
+                with torch.cuda.stream(copy_stream):
+                    dst.copy_(t, non_blocking=True)
+                t.record_stream(copy_stream)
+            return dst
+
+        side = torch.cuda.Stream(device=device) if (self.native and self.pinned) else None
+        rgb_h, disp_h = to_host("rgb", self.rgb, side), to_host("disparity", self.disp, side)
+        pointmaps = torch.empty((total, H, W, 3), dtype=torch.float64, device=device)
+        if self.native:
+            self._lib.check(self.lib.aether_backproject(self.disp.data_ptr(), K_inv.contiguous().data_ptr(), P.contiguous().data_ptr(), pointmaps.data_ptr(),
+                                                        total, H, W, torch.cuda.current_stream(device).cuda_stream), "aether_backproject")
+        else:
+            v, u = torch.meshgrid(torch.arange(H, device=device), torch.arange(W, device=device), indexing="ij")
+            pix = torch.stack([u.reshape(-1) + 0.5, v.reshape(-1) + 0.5, torch.ones(H * W, device=device)], 0).float().double()   # [3, HW]
+            step = 16
+            for i in range(0, total, step):
+                j = min(i + step, total)
+                depth = (1 / self.disp[i:j].clamp(1e-8, 1e8)).reshape(j - i, 1, H * W)
+                cam = (K_inv[i:j] @ pix) * depth                                                         # [n, 3, HW]
+                world = P[i:j, :, :3] @ cam + P[i:j, :, 3:]                                               # [n, 3, HW]
+                pointmaps[i:j] = world.transpose(1, 2).reshape(j - i, H, W, 3)
+        pm_h = to_host("pointmaps", pointmaps)
+        if self.native:
+            if side is not None:
+                torch.cuda.current_stream(device).wait_stream(side)
+            torch.cuda.current_stream(device).synchronize()
+        return rgb_h.numpy(), disp_h.numpy(), self.poses, pm_h.numpy()
+
+
+def _merge_on_device(results: Sequence[WindowResult], *, height: int, width: int, smooth_camera: bool, smooth_method: str,
+                     device: torch.device, out_dtype=np.float64, pinned: bool = False):
+    """blend_and_merge_window_results(device=...): every window through a WindowMerger, in order."""
+    first = results[0]
+    m = WindowMerger(total_frames=results[-1].start + results[-1].rgb.shape[0], window_frames=first.rgb.shape[0], frame_hw=tuple(first.disparity.shape[1:]),
+                     height=height, width=width, device=device, smooth_camera=smooth_camera, smooth_method=smooth_method, out_dtype=out_dtype, pinned=pinned)
+    for r in results:
+        m.add(r)
+    return m.finish()
 
 
 def _host(a):

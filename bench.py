@@ -218,30 +218,55 @@ def clip_wall_clock(transformer, dev, steps):
         if label != "warmup":
             out[label] = {"seconds": time.perf_counter() - t0, "steps": n}
         assert res.rgb.shape == (41, 480, 720, 3) and np.isfinite(res.rgb).all() and np.isfinite(res.disparity).all()
+    # BASELINE configs[2] / configs[3] on their NAMED inputs, exactly the sequence scripts/demo.py runs for them (D:564-606): the guided call
+    # (50 steps, B = 2 through the transformer, dynamic classifier-free guidance: the per-task defaults P:257-272) followed by the 4-step
+    # post-reconstruction of the generated clip (`--post_reconstruction`, D:581-606: disparity and raymap come from that second call).
+    named = os.path.join(ROOT, "tests", "golden", "named_inputs.npz")
+    if os.path.exists(named):
+        import PIL.Image
+
+        from aether_amd.geometry import forward_right_raymap
+        z = np.load(named)
+        img = lambda k: PIL.Image.fromarray(z[k])  # noqa: E731
+        cases = (("prediction", dict(image=img("car"), raymap=forward_right_raymap()), "car.png + forward-right raymap (camera_pose_to_raymap)"),
+                 ("planning", dict(image=img("obs01"), goal=img("goal01")), "01_obs.png + 01_goal.png"))
+        for task, kw, what in cases:
+            for label, n in (("warmup", 1), ("timed", steps)):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                gen_out = pipe(task=task, height=480, width=720, num_frames=41, fps=12, num_inference_steps=n,
+                               generator=torch.Generator(device=dev).manual_seed(42), **kw)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                rec = pipe(task="reconstruction", video=gen_out.rgb, height=480, width=720, num_frames=41, fps=12, num_inference_steps=4,
+                           guidance_scale=1.0, use_dynamic_cfg=False, generator=torch.Generator(device=dev).manual_seed(42))
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                assert gen_out.rgb.shape == (41, 480, 720, 3) and np.isfinite(gen_out.rgb).all() and np.isfinite(rec.disparity).all()
+                if label == "timed":
+                    out[f"{task}_{steps}_steps_cfg_plus_post_reconstruction"] = {
+                        "seconds": t2 - t0, "guided_call_seconds": t1 - t0, "post_reconstruction_seconds": t2 - t1, "steps": n,
+                        "inputs": what, "guidance": "dynamic CFG, scale 3.0, B = 2 through the DiT (per-task defaults P:257-272)"}
     out["unit"] = "s per 41f 480x720 clip (VAE encode + steps + 2 decodes + D2H), 1 GPU"
     return out
 
 
-def windows_mode(args, dev, rank, world, dist):
+def windows_run(args, dev, rank, world, dist, transformer=None):
     """BASELINE configs[4]: long-video reconstruction — 192 synthetic frames = 8 sliding 41-frame windows (stride 24, starts
-    0..144 + 151, scripts/demo.py:235-251), window w on rank w mod N, ONE gather of the device-resident outputs to rank 0
-    (RCCL; with N = 1 the same gather runs in a one-rank nccl group so the code path is exercised), merge on the device."""
+    0..144 + 151, scripts/demo.py:235-251), window w on rank w mod N, one gather of the device-resident outputs to rank 0 per ROUND of
+    windows (RCCL; with N = 1 the same gathers run in a one-rank nccl group so the code path is exercised), rank 0 merging round j on the
+    device while round j + 1 is computed (aether_amd.windows.run_windows_merged); merged arrays float32 into pinned host buffers
+    (scripts/demo.py's default; the reference's float64 with --float64_outputs).  Returns the result dict on rank 0, None elsewhere."""
     import numpy as np
 
     from aether.pipelines.aetherv1_pipeline_cogvideox import AetherV1PipelineCogVideoX
     from aether_amd.scheduler import CogVideoXDPMScheduler
     from aether_amd.transformer import AetherTransformer3D
     from aether_amd.vae import AetherVAE
-    from aether_amd.windows import blend_and_merge_window_results, get_window_starts, run_windows
+    from aether_amd.windows import get_window_starts, run_windows_merged
 
-    own_group = dist is None
-    if own_group:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    transformer = AetherTransformer3D({"num_layers": args.layers}, device=dev).init_random_weights(seed=0)
+    if transformer is None:
+        transformer = AetherTransformer3D({"num_layers": args.layers}, device=dev).init_random_weights(seed=0)
     vae = AetherVAE(device=dev).init_random_weights(1)
     vae.enable_slicing(); vae.enable_tiling()
     g = torch.Generator().manual_seed(0)
@@ -260,27 +285,91 @@ def windows_mode(args, dev, rank, world, dist):
         return pipe(task="reconstruction", video=video[s0:s0 + 41], height=480, width=720, num_frames=41,
                     num_inference_steps=args.window_steps, fps=12, generator=torch.Generator(device=dev).manual_seed(42))
 
-    call_window(0)                                           # warm-up (allocations, first-touch)
+    call_window(0)                                           # warm-up (allocations, first-touch, hipGraph capture)
+    if rank == 0:                                            # the page-locked output buffers exist before the clock starts (like every workspace)
+        from aether_amd import windows as W_
+        for tag, shp in (("rgb", (n_frames, 480, 720, 3)), ("disparity", (n_frames, 480, 720)), ("pointmaps", (n_frames, 480, 720, 3))):
+            W_._pinned(tag, shp, torch.float32)
+    dist.barrier(); torch.cuda.synchronize()
+    tm = {}
+    t0 = time.perf_counter()
+    merged = run_windows_merged(call_window, starts, height=480, width=720, gather_device=dev, out_dtype=np.float32, pinned=True,
+                                force_collective=True, timings=tm)
+    torch.cuda.synchronize()
+    t_total = time.perf_counter() - t0
+    out = None
+    if rank == 0:
+        rgb, disp, poses, pointmaps = merged
+        assert rgb.shape == (n_frames, 480, 720, 3) and np.isfinite(disp).all() and np.isfinite(pointmaps).all()
+        out = {"seconds_per_192_frame_clip": t_total, "windows_and_gather": tm["windows_and_gather"], "merge_tail_incl_d2h": tm["merge_tail"],
+               "windows": len(starts), "window_starts": starts, "sampler_steps_per_window": args.window_steps, "n_gpus": world,
+               "windows_per_rank": -(-len(starts) // world), "merged_dtype": "float32 (pinned host buffers)",
+               "gather": f"one dist.gather(dst=0) of device tensors per round of {world} window(s), backend {dist.get_backend()}; "
+                         "rank 0 merges round j on a side stream while round j+1 is computed",
+               "workload": "configs[4]: long-video reconstruction, 8 windows x 41 frames, stride 24"}
+    dist.barrier()
+    del pipe, vae
+    torch.cuda.empty_cache()
+    return out
+
+
+def windows_mode(args, dev, rank, world, dist):
+    """`bench.py --windows`: BASELINE configs[4] end to end instead of the step benchmark; prints its own JSON line."""
+    own_group = dist is None
+    if own_group:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    d = windows_run(args, dev, rank, world, dist)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "wall-clock per 192-frame 480x720 clip (8 sliding 41f windows + temporal blend)", "value": d["seconds_per_192_frame_clip"], "unit": "s",
+            "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": d["seconds_per_192_frame_clip"] * 1e3, "higher_is_better": False, "scaling": "strong",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic (192 smooth frames; random-init weights)",
+            "config": {"workload": d["workload"], "valid": args.layers == 42}, "windows": d}), flush=True)
+    dist.destroy_process_group()
+
+
+def cfg_parallel_leg(args, dev, rank, dist, model, steps):
+    """N = 2 only: ONE guided denoise step split over the two ranks: rank 0 evaluates the unconditional branch, rank 1
+    the conditional one at batch 1, ONE all-gather of the bf16 noise prediction (6.65 MB per rank) per step over RCCL, identical combine + DPM
+    step on both.  Times `steps` steps of exactly the pipeline's loop body (aether_amd pipeline `_gather_pair`)."""
+    from aether_amd.scheduler import CogVideoXDPMScheduler, randn_tensor
+    from aether_amd.rope import resize_crop_region_for_grid, rotary_tables_3d
+    c = model.config
+    F_, H_, W_ = 11, 60, 90
+    gen = torch.Generator(device=dev).manual_seed(42)          # the SAME seed on both ranks: the latents stay replicated without a broadcast
+    prompt = (torch.randn(1, c.max_text_seq_length, c.text_embed_dim, generator=gen, device=dev) * 0.1).to(torch.bfloat16)
+    cond = torch.randn(2, F_, 40, H_, W_, generator=gen, device=dev).to(torch.bfloat16)[rank:rank + 1]
+    latents = randn_tensor((1, F_, 56, H_, W_), generator=gen, device=dev, dtype=torch.bfloat16)
+    rope = rotary_tables_3d(64, resize_crop_region_for_grid((H_ // 2, W_ // 2), c.sample_width // 2, c.sample_height // 2), (H_ // 2, W_ // 2), F_, 1.0, device=dev)
+    sched = CogVideoXDPMScheduler()
+    sched.set_timesteps(50, device=dev)
+    ts = sched.timesteps.tolist()
+    old = None
+
+    def one(i, latents, old):
+        model_in = torch.cat([latents, cond], dim=2)
+        pred = model(hidden_states=model_in, encoder_hidden_states=prompt, timestep=sched.timesteps[i].expand(1), ofs=None, image_rotary_emb=rope,
+                     attention_kwargs=None, return_dict=False)[0]
+        parts = [torch.empty_like(pred) for _ in range(2)]
+        dist.all_gather(parts, pred.contiguous())
+        return sched.step_fused(torch.cat(parts), old, ts[i], ts[i - 1] if i > 0 else None, latents, guidance_scale=3.0, generator=gen)
+
+    latents, old = one(0, latents, old)
     dist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    results = run_windows(call_window, starts, gather_device=dev, keep_on_device=True, force_collective=True)
-    torch.cuda.synchronize()
-    t_windows = time.perf_counter() - t0
-    if rank == 0:
-        rgb, disp, poses, pointmaps = blend_and_merge_window_results(results, height=480, width=720, device=dev)
-        torch.cuda.synchronize()
-        t_total = time.perf_counter() - t0
-        assert rgb.shape == (n_frames, 480, 720, 3) and np.isfinite(disp).all() and np.isfinite(pointmaps).all()
-        print(json.dumps({
-            "metric": "wall-clock per 192-frame 480x720 clip (8 sliding 41f windows + temporal blend)", "value": t_total, "unit": "s",
-            "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": t_total * 1e3, "higher_is_better": False, "scaling": "strong",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic (192 smooth frames; random-init weights)",
-            "config": {"workload": "configs[4]: long-video reconstruction, 8 windows x 41 frames, stride 24", "window_starts": starts,
-                       "sampler_steps_per_window": args.window_steps, "windows_per_rank": -(-len(starts) // world),
-                       "gather": f"dist.gather(dst=0) of device tensors, backend {dist.get_backend()}", "valid": args.layers == 42},
-            "seconds": {"windows_and_gather": t_windows, "merge_incl_d2h": t_total - t_windows}}), flush=True)
-    dist.barrier()
-    dist.destroy_process_group()
+    for i in range(1, steps + 1):
+        latents, old = one(i, latents, old)
+    dist.barrier(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    chk = latents.float().sum().reshape(1)
+    both = [torch.empty_like(chk) for _ in range(2)]
+    dist.all_gather(both, chk)
+    return {"steps_per_s": steps / dt, "ms_per_step": dt / steps * 1e3, "ranks_hold_identical_latents": bool(torch.equal(both[0], both[1])),
+            "workload": "configs[2]/[3]: ONE guided step over 2 ranks (one guidance branch each at B = 1, all-gather of noise_pred over RCCL, DPM step)"}
 
 
 def windows_leg(args):
@@ -291,10 +380,7 @@ def windows_leg(args):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     for ln in reversed(r.stdout.splitlines()):
         if ln.startswith("{"):
-            d = json.loads(ln)
-            return {"seconds_per_192_frame_clip": d["value"], **d["seconds"], "windows": len(d["config"]["window_starts"]),
-                    "sampler_steps_per_window": d["config"]["sampler_steps_per_window"], "n_gpus": d["n_gpus"], "gather": d["config"]["gather"],
-                    "workload": d["config"]["workload"]}
+            return json.loads(ln)["windows"]
     return {"error": (r.stderr or r.stdout)[-400:]}
 
 
@@ -413,6 +499,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
     assert torch.isfinite(state["latents"].float()).all(), "non-finite latents"
+    # N > 1: the replica steps above say nothing about the one thing that shards WITH an exchange — BASELINE configs[4] (8 windows over the N
+    # ranks, RCCL gathers, device merge) runs in the SAME process group and is attached to the rank-0 line; N = 2 adds the guided step split
+    # over the two ranks.  Both legs are outside the timed region of `value`.
+    multi = {}
+    if dist is not None and not args.no_extra_legs:
+        if world == 2:
+            multi["cfg_parallel_step"] = cfg_parallel_leg(args, dev, rank, dist, model, args.steps)
+        multi["windows"] = windows_run(args, dev, rank, world, dist, transformer=model)
 
     if rank == 0:
         steps_per_s = world * args.steps / elapsed
@@ -440,30 +534,26 @@ def main():
                               if flops_per_launch(k, B, S, D, FF) > 0 and ms > 0},
             "gpu_kernel_ms_per_step_total": total_ms / args.steps,
         }
+        line.update({k: v for k, v in multi.items() if v is not None})
         if world == 1 and not args.no_extra_legs:
-            # The attention soft-max is exact on every path (include/aether_hip.h); what differs is the loop.  Legs, each `--steps` timed
-            # steps: the default (tile-pair pipeline, optimistic shift-0 sweep, Q fragments in registers), the same without the Q
-            # registers (round 2's loop), the 64-rows-per-wave kernel with 256- and 512-row workgroups, the CONSERVATIVE path (true-maximum
-            # shift from the first tile, a-posteriori check per tile: no dependence on the data or the weights = the floor), and the worst
-            # case of the default path: q/k-norm weights x10 (log2-domain scores of several hundred: every workgroup's optimistic sweep is
-            # thrown away and redone on the conservative path).
+            # The attention soft-max is exact on every path (include/aether_hip.h).  Legs, each `--steps` timed steps: the default
+            # (optimistic shift-0 tile-pair sweep), the CONSERVATIVE path alone (true-maximum shift from the first tile, a-posteriori
+            # check per tile: no dependence on the data or the weights = the floor), and the worst case of the default path: q/k-norm
+            # weights x10 (log2-domain scores of several hundred: every workgroup's optimistic sweep is thrown away and redone).
             from aether_amd import _lib as L_
             att = lambda pr: round(flops_per_launch("attention", B, S, D, FF) * pr["attention"][1] / (pr["attention"][0] * 1e-3) / 1e12, 1)  # noqa: E731
             paths = {"default": {"steps_per_s": steps_per_s, "attention_tflops": line["kernel_tflops"].get("attention")}}
             fl0 = model._flags
-            base = fl0 & ~(L_.AETHER_ATTN_ROWS64 | L_.AETHER_ATTN_WG512 | L_.AETHER_ATTN_PAIR_PIPELINE | L_.AETHER_ATTN_QREG | L_.AETHER_ATTN_INTERLEAVE)
-            for name, fl in (("tile_pair_q_from_lds_round2", base | L_.AETHER_ATTN_PAIR_PIPELINE),
-                             ("rows64_256_row_workgroups", base | L_.AETHER_ATTN_ROWS64),
-                             ("rows64_512_row_workgroups", base | L_.AETHER_ATTN_ROWS64 | L_.AETHER_ATTN_WG512),
-                             ("conservative_path_data_independent", fl0 | L_.AETHER_ATTN_EXACT_MAX)):
-                model.set_flags(fl)
-                dt, pr = timed(1, args.steps)
-                paths[name] = {"steps_per_s": args.steps / dt, "attention_tflops": att(pr)}
+            model.set_flags(fl0 | L_.AETHER_ATTN_EXACT_MAX)
+            dt, pr = timed(1, args.steps)
+            paths["conservative_path_data_independent"] = {"steps_per_s": args.steps / dt, "attention_tflops": att(pr)}
             model.set_flags(fl0)
+            saved = {k: model._weights[k].clone() for k in ("qn_w", "kn_w")}          # restored bit-exactly below (x10 then /10 is not)
             model._weights["qn_w"].mul_(10.0); model._weights["kn_w"].mul_(10.0)
             dt, pr = timed(1, args.steps)
             paths["worst_case_every_workgroup_redoes_qk_norm_x10"] = {"steps_per_s": args.steps / dt, "attention_tflops": att(pr)}
-            model._weights["qn_w"].div_(10.0); model._weights["kn_w"].div_(10.0)
+            for k, v in saved.items():
+                model._weights[k].copy_(v)
             line["attention_paths"] = paths
             # BASELINE configs[2] / [3] (prediction / planning): classifier-free guidance = B = 2 through the transformer + the combine
             state.update(B=2, i=0, old_x0=None)

@@ -30,7 +30,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from aether.pipelines.aetherv1_pipeline_cogvideox import AetherV1PipelineCogVideoX  # noqa: E402
 from aether_amd.export import colorize_depth, flip_for_export, output_stem, write_video  # noqa: E402
-from aether_amd.windows import WindowResult, blend_and_merge_window_results, get_window_starts, run_windows  # noqa: E402
+from aether_amd.windows import WindowResult, blend_and_merge_window_results, get_window_starts, run_windows, run_windows_merged  # noqa: E402
 
 
 def seed_all(seed: int = 0) -> None:
@@ -81,6 +81,8 @@ def parse_args(argv=None) -> argparse.Namespace:
     p.add_argument("--empty_prompt_embeds", type=str, default=None, help="[aether_amd] .pt file with the T5 embedding of the empty prompt [1,226,4096].")
     p.add_argument("--synthetic_weights", action="store_true", default=False, help="[aether_amd] seeded random weights instead of checkpoints (smoke runs).")
     p.add_argument("--synthetic_layers", type=int, default=42, help="[aether_amd] depth of the synthetic transformer.")
+    p.add_argument("--float64_outputs", action="store_true", default=False,
+                   help="[aether_amd] merged arrays of a long clip as float64 like the reference's numpy merge (default float32: half the D2H bytes).")
     return p.parse_args(argv)
 
 
@@ -234,9 +236,17 @@ def main(argv=None) -> None:
 
         # window outputs never leave HBM between the pipeline, the gather to rank 0 (RCCL) and the device merge
         pipeline.keep_outputs_on_device = not args.align_pointmaps
-        results = run_windows(call_window, starts, gather_device=device, keep_on_device=not args.align_pointmaps)
-        if results is not None:
-            rgb, disparity, poses, pointmaps = merge(args, results, device)
+        if args.align_pointmaps:
+            # the reference's point-map alignment branch stays on the host (numpy): gather everything, then merge
+            results = run_windows(call_window, starts, gather_device=device, keep_on_device=False)
+            merged = merge(args, results, device) if results is not None else None
+        else:
+            # rounds of one window per rank; rank 0 merges round j on a side stream while round j + 1 is computed (aether_amd.windows)
+            merged = run_windows_merged(call_window, starts, height=args.height, width=args.width, gather_device=device,
+                                        smooth_camera=args.smooth_camera, smooth_method=args.smooth_method,
+                                        out_dtype=np.float64 if args.float64_outputs else np.float32, pinned=True)
+        if merged is not None:
+            rgb, disparity, poses, pointmaps = merged
             save_output(args, rgb=rgb, disparity=disparity, poses=poses, pointmap=pointmaps, window_starts=np.asarray(starts))
     if world > 1:
         import torch.distributed as dist

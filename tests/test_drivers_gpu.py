@@ -215,7 +215,7 @@ _NCCL_WORKER = textwrap.dedent('''
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    from aether_amd.windows import blend_and_merge_window_results, get_window_starts, run_windows
+    from aether_amd.windows import blend_and_merge_window_results, get_window_starts, run_windows, run_windows_merged
     from aether_amd.geometry import camera_pose_to_raymap
     H, W, F = 48, 72, 17
     rng = np.random.default_rng(0)
@@ -237,6 +237,15 @@ _NCCL_WORKER = textwrap.dedent('''
     devm = blend_and_merge_window_results(coll, height=H, width=W, smooth_camera=False, device=dev)
     for x, y, tol in zip(host, devm, (1e-6, 1e-5, 1e-9, 1e-4)):
         assert np.allclose(np.asarray(x), np.asarray(y), rtol=tol, atol=tol), float(np.abs(np.asarray(x) - np.asarray(y)).max())
+    # the pipelined form (one nccl gather per round of windows, rank 0 merging round j on a side stream while round j + 1 runs): the same values,
+    # as float64 and as float32 into pinned host buffers
+    t = {}
+    m64 = run_windows_merged(call, starts, height=H, width=W, gather_device=dev, smooth_camera=False, force_collective=True, timings=t)
+    m32 = run_windows_merged(call, starts, height=H, width=W, gather_device=dev, smooth_camera=False, force_collective=True, out_dtype=np.float32, pinned=True)
+    assert "merge_tail" in t
+    for x, y, z in zip(devm, m64, m32):
+        assert np.array_equal(np.asarray(x), np.asarray(y)), float(np.abs(np.asarray(x) - np.asarray(y)).max())
+        assert np.array_equal(np.asarray(y).astype(np.float32) if z.dtype == np.float32 else np.asarray(y), z)
     # the guidance split's exchange (pipeline._gather_pair): an all_gather of bf16 device tensors over nccl
     from aether.pipelines.aetherv1_pipeline_cogvideox import AetherV1PipelineCogVideoX
     pipe = AetherV1PipelineCogVideoX.__new__(AetherV1PipelineCogVideoX)

@@ -9,8 +9,8 @@
 Weights and inputs are regenerated here from the seeds of tools/fullsize_cases.py (CPU generators, bf16-representable), so both
 sides saw identical bits.  The oracle is this repo's restatement of diffusers (PARITY UNPINNED against diffusers itself, DESIGN §2);
 what these tests bound is the drift of the bf16 HIP path from an fp32 evaluation of the same arithmetic at the real depth and size.
-Thresholds = ~2x the values measured on MI355X (profiles/r03_parity_fullsize.log), which in turn sit at the bf16-oracle distance
-of the scaled-down end-to-end tests (tests/test_pipeline_gpu.py).
+Thresholds: the DiT must stay within the distance of the bf16 ORACLE itself from the same fixture (1.50e-2 / 2.24 %,
+profiles/r03_bf16_oracle_calibration.json); the VAE / clip bounds are ~1.3x the values measured on MI355X (profiles/r03_parity_fullsize.log).
 """
 import gc
 import json
@@ -74,7 +74,8 @@ def test_dit_42_blocks_full_sequence(cuda, native_dit):
     print(f"\n[fullsize] DiT {meta['layers']} blocks, S = {fc.TEXT_LEN + fc.LAT_F * fc.LAT_H * fc.LAT_W // 4}, B = 1 vs fp32 oracle "
           f"({meta['seconds_cpu']:.0f} s of CPU offline): rel-L2 {m['rel_l2']:.3e}  latents L-inf {m['linf']:.4f} "
           f"({100 * m['linf_rel']:.2f} % of max|ref| {m['ref_max']:.3f})")
-    assert m["rel_l2"] <= 2.2e-2 and m["linf_rel"] <= 0.04, m        # measured 1.08e-2 / 1.73 % (profiles/r03_parity_fullsize.log)
+    # measured 1.08e-2 / 1.73 %; the bound is the bf16 oracle's own distance to this fixture (1.50e-2 / 2.24 %): no worse than the reference dtype
+    assert m["rel_l2"] <= 1.50e-2 and m["linf_rel"] <= 0.023, m
 
 
 def test_vae_encode_whole_clip(cuda, native_vae):
@@ -89,8 +90,8 @@ def test_vae_encode_whole_clip(cuda, native_vae):
     m, ml = fc.metrics(mean, ref_mean), fc.metrics(logvar[..., ::2, ::2], ref_logvar)
     print(f"\n[fullsize] VAE encode {fc.FRAMES}x{fc.HEIGHT}x{fc.WIDTH}, all tiles and chunks, vs fp32 oracle: posterior mean rel-L2 {m['rel_l2']:.3e}  "
           f"latents L-inf {m['linf']:.4f} ({100 * m['linf_rel']:.2f} % of max|ref| {m['ref_max']:.3f}); log-variance L-inf {100 * ml['linf_rel']:.2f} %")
-    assert m["rel_l2"] <= 2.0e-2 and m["linf_rel"] <= 0.04, m        # measured 1.13e-2 / 1.80 %; log-variance 1.35 %
-    assert ml["linf_rel"] <= 0.04, ml
+    assert m["rel_l2"] <= 1.5e-2 and m["linf_rel"] <= 0.024, m       # measured 1.13e-2 / 1.80 %; log-variance 1.35 %
+    assert ml["linf_rel"] <= 0.018, ml
 
 
 def test_vae_decode_whole_clip(cuda, native_vae):
@@ -108,7 +109,7 @@ def test_vae_decode_whole_clip(cuda, native_vae):
     p = fc.psnr((got / 2 + 0.5).clamp(0, 1), (ref / 2 + 0.5).clamp(0, 1))
     print(f"\n[fullsize] VAE decode {fc.LAT_F}x{fc.LAT_H}x{fc.LAT_W} -> {fc.FRAMES}x{fc.HEIGHT}x{fc.WIDTH}, all tiles and chunks (every {s}th row/column compared): "
           f"rel-L2 {m['rel_l2']:.3e}  L-inf {m['linf']:.4f}  pixel PSNR {p:.1f} dB")
-    assert p >= 42.0 and m["rel_l2"] <= 1.5e-2, (p, m)              # measured 49.5 dB / 6.2e-3
+    assert p >= 47.2 and m["rel_l2"] <= 8.1e-3, (p, m)              # measured 49.5 dB / 6.2e-3 (1.3x the error = -2.3 dB)
 
 
 def test_reconstruction_clip_four_steps(cuda, native_dit, native_vae):
@@ -140,5 +141,5 @@ def test_reconstruction_clip_four_steps(cuda, native_dit, native_vae):
           f"rgb PSNR {p_rgb:.1f} dB; disparity rel-L2 {m_disp['rel_l2']:.3e}; raymap rel-L2 {m_ray['rel_l2']:.3e}")
     assert out.rgb.shape == (fc.FRAMES, fc.HEIGHT, fc.WIDTH, 3) and np.isfinite(out.rgb).all()
     # measured: latents 1.03e-2 / 1.53 %, rgb 39.1 dB, disparity 2.2e-2 (a squared quantity: twice the relative error), raymap 9.6e-3
-    assert ml["rel_l2"] <= 2.2e-2 and ml["linf_rel"] <= 0.04, ml
-    assert p_rgb >= 34.0 and m_disp["rel_l2"] <= 4.5e-2 and m_ray["rel_l2"] <= 2.2e-2, (p_rgb, m_disp, m_ray)
+    assert ml["rel_l2"] <= 1.35e-2 and ml["linf_rel"] <= 0.02, ml
+    assert p_rgb >= 36.8 and m_disp["rel_l2"] <= 2.9e-2 and m_ray["rel_l2"] <= 1.25e-2, (p_rgb, m_disp, m_ray)

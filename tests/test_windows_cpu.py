@@ -127,3 +127,56 @@ def test_export_names_colour_map_and_flips(tmp_path):
     assert set(out.files) == {"rgb", "disparity", "pointmap", "poses"} and np.array_equal(out["poses"], fposes)
     assert any(f.name.startswith("prediction_car_rgb") for f in tmp_path.iterdir())
     assert any(f.name.startswith("prediction_car_disparity") for f in tmp_path.iterdir())
+
+
+_MERGED_WORKER = textwrap.dedent('''
+    import os, sys
+    import numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, %(root)r)
+    from types import SimpleNamespace
+    from aether_amd.windows import WindowResult, blend_and_merge_window_results, run_windows, run_windows_merged
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo")
+    G = np.load(os.path.join(%(root)r, "tests", "golden", "blend.npz"))
+    H, W = (int(v) for v in G["hw"])
+    starts = [int(s) for s in G["starts"]]
+    def call(s):      # the three overlapping windows of the reference-made blend fixture (valid raymaps: the merge fits cameras on them)
+        k = starts.index(s)
+        return SimpleNamespace(rgb=G[f"rgb_{k}"].astype(np.float32), disparity=G[f"disparity_{k}"].copy(), raymap=G[f"raymap_{k}"].copy())
+    t = {}
+    merged = run_windows_merged(call, starts, height=H, width=W, smooth_camera=False, timings=t, force_collective=%(force)r)
+    assert "windows_and_gather" in t
+    if merged is not None:
+        np.savez(%(out)r, rgb=merged[0], disparity=merged[1], poses=merged[2], pointmaps=merged[3])
+        f32 = None
+    res = run_windows(call, starts)
+    if res is not None:
+        ref = blend_and_merge_window_results(res, height=H, width=W, smooth_camera=False, device="cpu")
+        for a, b in zip(merged, ref):
+            assert a.dtype == np.float64 and np.array_equal(a, b)
+    m32 = run_windows_merged(call, starts, height=H, width=W, smooth_camera=False, out_dtype=np.float32)
+    if m32 is not None:
+        assert m32[0].dtype == np.float32 and m32[3].dtype == np.float32 and np.array_equal(m32[0], merged[0].astype(np.float32))
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+''')
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_gloo_round_wise_gather_and_incremental_merge(tmp_path, world):
+    """`run_windows_merged` (what scripts/demo.py and bench.py run for a long clip): one gather per ROUND of windows, rank 0 merges a round
+    while the next one is computed.  3 windows on 1 / 2 / 4 ranks (uneven rounds; more ranks than windows): bit-identical to the gather-at-the-
+    end path, and equal to the reference's own merge of the same windows (tests/golden/blend.npz)."""
+    out = str(tmp_path / f"m{world}.npz")
+    script = tmp_path / f"mworker{world}.py"
+    script.write_text(_MERGED_WORKER % dict(root=ROOT, out=out, force=False))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, str(script)] if world == 1 else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                                                            "--master-addr", "127.0.0.1", "--master-port", "29519", str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got, gold = np.load(out), np.load(os.path.join(ROOT, "tests", "golden", "blend.npz"))
+    for k, ref in (("rgb", "plain_rgb"), ("disparity", "plain_disparity"), ("poses", "plain_poses"), ("pointmaps", "plain_pointmaps")):
+        err = np.abs(got[k] - gold[ref]).max() / np.abs(gold[ref]).max()
+        assert err < 1e-5, (k, err)

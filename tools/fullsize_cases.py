@@ -156,16 +156,8 @@ def forward_right_raymap() -> np.ndarray:
     trajectory in the first frame's camera coordinates (the reference's own assets/example_raymaps/raymap_forward_right.npy is
     not part of the mount: .MISSING_LARGE_BLOBS): eased translation 0.6 forward (+z) and 0.3 to the right (+x), yaw to the right
     up to 15 degrees, 60-degree horizontal field of view."""
-    from aether_amd.geometry import camera_pose_to_raymap
-    s = np.linspace(0.0, 1.0, FRAMES, dtype=np.float64)
-    ease = s * s * (3 - 2 * s)
-    yaw = np.deg2rad(15.0) * ease
-    pose = np.tile(np.eye(4, dtype=np.float32), (FRAMES, 1, 1))
-    pose[:, 0, 0], pose[:, 0, 2], pose[:, 2, 0], pose[:, 2, 2] = np.cos(yaw), np.sin(yaw), -np.sin(yaw), np.cos(yaw)
-    pose[:, 0, 3], pose[:, 2, 3] = 0.3 * ease, 0.6 * ease
-    K = np.tile(np.array([[WIDTH / 2 / np.tan(np.deg2rad(30.0)), 0, WIDTH / 2], [0, WIDTH / 2 / np.tan(np.deg2rad(30.0)), HEIGHT / 2],
-                          [0, 0, 1]], np.float32), (FRAMES, 1, 1))
-    return camera_pose_to_raymap(pose, K, H=HEIGHT, W=WIDTH)
+    from aether_amd.geometry import forward_right_raymap as make
+    return make(FRAMES, HEIGHT, WIDTH)
 
 
 GUIDED_CASES = {

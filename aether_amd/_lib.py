@@ -18,6 +18,7 @@ AETHER_GEMM_WIDE_STORE = 1
 AETHER_GEMM_SPLIT_LONE_TAIL = 2   # a launch of 64..128 tiles with K >= 2048 also splits its K loop (fused-qkv remainder only)
 AETHER_DIT_FUSE_QKV_PREP = 65536  # aether_dit_forward: q/k norm + RoPE + V transpose in the qkv GEMM's epilogue
 AETHER_ATTN_EXACT_MAX = 32    # attention: conservative path only (true-maximum shift from tile 0, a-posteriori check per tile)
+AETHER_VAE_TWO_LANES = 256    # VAE plan: tile batches of two on two streams (see include/aether_hip.h)
 AETHER_CONV_TAP_REUSE = 128   # conv: K order is (dt, dh, channel block, dw) -> the tap-reuse kernel may be used
 ATTN_Q_SCALE = 0.125 * 1.4426950408889634   # softmax scale x log2(e): the attention kernel works in the log2 domain
 PROF_CLASSES = ["other", "layernorm", "gemm_qkv", "qk_norm_rope", "attention", "gemm_out", "gemm_ff1", "gemm_ff2"]

@@ -32,7 +32,7 @@ struct NormW {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-typedef std::tuple<int, int, int, int, int> Shape5;
+typedef std::tuple<int, int, int, int, int, int> Shape5;   // (lane, NB, T, H, W, C)
 
 }  // namespace
 
@@ -45,9 +45,13 @@ struct AetherVae {
     // are written once (zeroed when the shape is first seen in THIS workspace) and never again — producers write interiors only.
     char* ws = nullptr; size_t ws_bytes = 0;
     std::map<Shape5, size_t> pool;        // shape -> byte offset inside the pool region
-    std::map<std::tuple<int, int, int, int, int, int>, size_t> taps;   // (kt,kh,kw,iH,iW,iC) -> offset (int32 table, device generated)
+    std::map<std::tuple<int, int, int, int, int, int, int>, size_t> taps;   // (lane,kt,kh,kw,iH,iW,iC) -> offset (int32 table, device generated)
     size_t pool_bytes = 0;                // bytes of the pool region in use
     size_t pool_cap = 0;                  // pool region size of the current workspace
+    // ---- second lane (AETHER_VAE_TWO_LANES): the tile groups of one call are independent; half of them are enqueued on a stream of the
+    // handle's own, forked from / joined to the caller's stream with events (capturable: the side stream joins the caller's capture)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 namespace {
@@ -170,8 +174,12 @@ struct Plan {
     size_t top = 0, peak = 0;
     size_t pool_need = 0;     // dry: pool bytes after this call
     std::map<Shape5, size_t> dry_pool;
-    std::map<std::tuple<int, int, int, int, int, int>, size_t> dry_taps;
+    std::map<std::tuple<int, int, int, int, int, int, int>, size_t> dry_taps;
     float* splitk = nullptr; size_t splitk_bytes = 0;
+    int lane = 0;                     // lane whose groups are being enqueued: selects `stream`, `splitk` and the pool entries
+    hipStream_t lane_stream[2] = {nullptr, nullptr};
+    float* lane_splitk[2] = {nullptr, nullptr};
+    void set_lane(int l) { lane = l; stream = lane_stream[l]; splitk = lane_splitk[l]; }
     int rc = 0;
     std::string err;
 
@@ -197,7 +205,7 @@ struct Plan {
 
     // pool: zero-bordered volume of this shape (persistent across calls in one workspace)
     char* padded(int NB, int T, int H, int W, int C) {
-        const Shape5 key(NB, T, H, W, C);
+        const Shape5 key(lane, NB, T, H, W, C);
         const size_t bytes = align_up((size_t)NB * T * H * W * C * 2, 256);
         if (dry) {
             if (h->pool.count(key) || dry_pool.count(key)) return reinterpret_cast<char*>((uintptr_t)256);
@@ -214,7 +222,7 @@ struct Plan {
         return h->ws + it->second;
     }
     const int* tap_table(int kt, int kh, int kw, int iH, int iW, int iC, int* n_taps) {
-        const auto key = std::make_tuple(kt, kh, kw, iH, iW, iC);
+        const auto key = std::make_tuple(lane, kt, kh, kw, iH, iW, iC);
         const int n = kt * kh * kw * (iC / 64);
         *n_taps = n;
         const size_t bytes = align_up((size_t)n * 4, 256);
@@ -469,15 +477,18 @@ struct Plan {
         const auto ch = chunks(T, bs);
         const int To = total_out_frames(c, decode, T);
         const int oC = decode ? c.out_channels : 2 * c.latent_channels;
-        // groups of equally shaped tiles
-        struct Group { int th, tw; std::vector<int> idx; };
+        // groups of equally shaped tiles: up to 4 per launch batch on one lane, up to 2 with two lanes (every tile's arithmetic is
+        // independent of its batch: GroupNorm statistics are per batch item, a convolution row depends on its own voxels only)
+        const bool two_lanes = (c.flags & AETHER_VAE_TWO_LANES) != 0 && nrow * ncol > 1;
+        const size_t gmax = two_lanes ? 2 : 4;
+        struct Group { int th, tw; std::vector<int> idx; int lane = 0; };
         std::vector<Group> groups;
         for (int i = 0; i < nrow; ++i)
             for (int j = 0; j < ncol; ++j) {
                 const int th = std::min(th0, H - rows_y[i]), tw = std::min(tw0, W - cols_x[j]);
                 bool found = false;
-                for (auto& g : groups) if (g.th == th && g.tw == tw && g.idx.size() < 4) { g.idx.push_back(i * ncol + j); found = true; break; }
-                if (!found) groups.push_back(Group{th, tw, {i * ncol + j}});
+                for (auto& g : groups) if (g.th == th && g.tw == tw && g.idx.size() < gmax) { g.idx.push_back(i * ncol + j); found = true; break; }
+                if (!found) groups.push_back(Group{th, tw, {i * ncol + j}, 0});
             }
         AsmArgs asmargs{};
         int ldc = 0;
@@ -493,8 +504,27 @@ struct Plan {
             oth[k] = decode ? th * down : th / down; otw[k] = decode ? tw * down : tw / down;
             full[k] = alloc((size_t)To * oth[k] * otw[k] * ldc * 2);
         }
-        const size_t mark_call = top;
-        for (auto& g : groups) {
+        // lanes: groups in order of decreasing area, each to the lane with less work so far (480x720: two groups of two full tiles,
+        // then 2 x (240x144) | 2 x (80x360) + (80x144): 241.9k pixels of tiles per lane); lane 0 is enqueued on the caller's stream
+        if (two_lanes) {
+            std::vector<int> order(groups.size());
+            for (size_t i = 0; i < groups.size(); ++i) order[i] = (int)i;
+            auto area = [&](int i) { return (long)groups[i].th * groups[i].tw * (long)groups[i].idx.size(); };
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return area(a) > area(b); });
+            long load[2] = {0, 0};
+            for (int i : order) { const int l = load[1] < load[0] ? 1 : 0; groups[i].lane = l; load[l] += area(i); }
+            if (!dry) {
+                if (hipEventRecord(h->ev_fork, lane_stream[0]) != hipSuccess || hipStreamWaitEvent(lane_stream[1], h->ev_fork, 0) != hipSuccess)
+                    return fail(AETHER_ERR_LAUNCH, "vae: fork of the second lane failed");
+            }
+        }
+        size_t lane_base = top;
+        for (int pass = 0; pass < (two_lanes ? 2 : 1); ++pass) {
+          if (pass == 1) lane_base = align_up(peak, 256);            // lane 1's arena starts where lane 0's ends
+          set_lane(pass);
+          const size_t mark_call = lane_base;
+          for (auto& g : groups) {
+            if (g.lane != pass) continue;
             top = mark_call;
             const int NB = (int)g.idx.size();
             int crops[4][2];
@@ -536,6 +566,12 @@ struct Plan {
                 t_out += y.T;
             }
             if (t_out != To) return fail(AETHER_ERR_SHAPE, "vae: internal: frame count");
+          }
+        }
+        set_lane(0);
+        if (two_lanes && !dry) {
+            if (hipEventRecord(h->ev_join, lane_stream[1]) != hipSuccess || hipStreamWaitEvent(lane_stream[0], h->ev_join, 0) != hipSuccess)
+                return fail(AETHER_ERR_LAUNCH, "vae: join of the second lane failed");
         }
         caches = nullptr;
         // assemble
@@ -560,7 +596,7 @@ int vae_run(AetherVae* h, bool decode, const void* src, int T, int H, int W, int
             void* stream, size_t* need_out) {
     Plan dry; dry.h = h; dry.stream = nullptr; dry.dry = true;
     int oT, oH, oW;
-    dry.alloc(kVaeSplitKBytes);
+    dry.alloc(2 * kVaeSplitKBytes);
     if (!dry.run(decode, src, T, H, W, tiling, nullptr, &oT, &oH, &oW)) return aether_set_error(dry.rc, dry.err.c_str());
     const size_t pool_total = h->pool_bytes + dry.pool_need;
     const size_t need = align_up(pool_total, 256) + dry.peak;
@@ -571,7 +607,7 @@ int vae_run(AetherVae* h, bool decode, const void* src, int T, int H, int W, int
         h->ws = (char*)workspace; h->ws_bytes = workspace_bytes;
         h->pool.clear(); h->taps.clear(); h->pool_bytes = 0;
         // after a reset the pool must hold every shape of this call again
-        Plan d2; d2.h = h; d2.dry = true; d2.alloc(kVaeSplitKBytes);
+        Plan d2; d2.h = h; d2.dry = true; d2.alloc(2 * kVaeSplitKBytes);
         if (!d2.run(decode, src, T, H, W, tiling, nullptr, &oT, &oH, &oW)) return aether_set_error(d2.rc, d2.err.c_str());
         if (align_up(d2.pool_need, 256) + d2.peak > workspace_bytes) return aether_set_error(AETHER_ERR_ARG, "vae: workspace too small");
     }
@@ -579,7 +615,18 @@ int vae_run(AetherVae* h, bool decode, const void* src, int T, int H, int W, int
     Plan p; p.h = h; p.stream = (hipStream_t)stream; p.dry = false;
     p.arena = (char*)workspace + (workspace_bytes - align_up(dry.peak, 256)) / 256 * 256;
     h->pool_cap = (size_t)(p.arena - (char*)workspace);
-    p.splitk = (float*)p.alloc(kVaeSplitKBytes); p.splitk_bytes = kVaeSplitKBytes;
+    if ((h->cfg.flags & AETHER_VAE_TWO_LANES) && h->side == nullptr) {
+        // a HIGH-PRIORITY stream: priority streams get hardware queues of their own, a normal stream may share the caller's queue (4 queues,
+        // round robin) and then nothing overlaps (profiles/r03_decode_pair.json)
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, hi) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)
+            return aether_set_error(AETHER_ERR_LAUNCH, "vae: could not create the second lane's stream / events");
+    }
+    p.lane_stream[0] = (hipStream_t)stream; p.lane_stream[1] = h->side ? h->side : (hipStream_t)stream;
+    p.lane_splitk[0] = (float*)p.alloc(kVaeSplitKBytes); p.lane_splitk[1] = (float*)p.alloc(kVaeSplitKBytes); p.splitk_bytes = kVaeSplitKBytes;
+    p.set_lane(0);
     if (!p.run(decode, src, T, H, W, tiling, out, &oT, &oH, &oW)) return aether_set_error(p.rc, p.err.c_str());
     return AETHER_OK;
 }
@@ -597,7 +644,13 @@ extern "C" AetherVae* aether_vae_create(const AetherVaeConfig* cfg) {
     return h;
 }
 
-extern "C" void aether_vae_destroy(AetherVae* h) { delete h; }
+extern "C" void aether_vae_destroy(AetherVae* h) {
+    if (!h) return;
+    if (h->side) hipStreamDestroy(h->side);
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
+    delete h;
+}
 
 extern "C" int aether_vae_set_conv(AetherVae* h, const char* name, const void* w, const float* b, int cout, int cout_pad, int cin, int kt, int kh,
                                    int kw, int kcols, int blocked) {

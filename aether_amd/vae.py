@@ -115,7 +115,7 @@ class _Resnet:
 
 
 class AetherVAE:
-    def __init__(self, config: Optional[dict] = None, device="cuda", flags: int = _lib.AETHER_GEMM_WIDE_STORE):
+    def __init__(self, config: Optional[dict] = None, device="cuda", flags: int = _lib.AETHER_GEMM_WIDE_STORE | _lib.AETHER_VAE_TWO_LANES):
         cfg = dict(_CONFIG_DEFAULTS)
         cfg.update(config or {})
         cfg["block_out_channels"] = tuple(cfg["block_out_channels"])
@@ -620,7 +620,10 @@ class AetherVAE:
         for (y0, x0) in origins:
             groups.setdefault((min(tile_h, H - y0), min(tile_w, W - x0)), []).append((y0, x0))
         out = {}
-        for (th, tw), crops in groups.items():
+        # the C launch plan batches two tiles at a time when it runs two lanes (AETHER_VAE_TWO_LANES), four otherwise: the same batches here
+        gmax = 2 if (self._flags & _lib.AETHER_VAE_TWO_LANES) and len(origins) > 1 else 4
+        batches = [((th, tw), crops[i:i + gmax]) for (th, tw), crops in groups.items() for i in range(0, len(crops), gmax)]
+        for (th, tw), crops in batches:
             cache: Dict = {}
             pieces = []
             for k, (s, e) in enumerate(self._chunks(T, bs)):

@@ -276,8 +276,14 @@ typedef struct AetherVaeConfig {
     int sample_height, sample_width; /* 480, 720: tiles are half of it, overlaps 1/6 and 1/5 (diffusers) */
     float norm_eps;                  /* 1e-6 */
     float tap_reuse_max_waste;       /* padded-plane / output-plane ratio up to which the tap-reuse convolution runs (1.06) */
-    int flags;                       /* AETHER_GEMM_* flags forwarded to the GEMMs */
+    int flags;                       /* AETHER_GEMM_* flags forwarded to the GEMMs | AETHER_VAE_TWO_LANES */
 } AetherVaeConfig;
+#define AETHER_VAE_TWO_LANES 256 /* flags bit 8: the spatial tiles of one encode / decode (independent of each other until the cross-fade) are batched
+                                    two at a time instead of four, and the batches are enqueued on TWO streams — the caller's and one owned by the
+                                    handle (high priority, forked from / joined to the caller's stream by events; capturable) — balanced by tile area,
+                                    so that the small launches of one batch (512-channel levels at latent resolution, GroupNorm statistics, split-K
+                                    finalizes) fill the gaps of the other.  Same kernels, same per-tile arithmetic; a batch of two tiles may take
+                                    the split-K path where a batch of four did not (another fp32 summation order in those layers).               */
 
 typedef struct AetherVae AetherVae; /* opaque host-side handle: weight table + workspace bookkeeping */
 

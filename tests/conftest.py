@@ -33,3 +33,27 @@ def cuda():
 
     _lib.check(_lib.load().aether_check_device(), "aether_check_device")
     return torch.device("cuda:0")
+
+
+# ---- the seeded full-size modules (42-block DiT, real-width VAE) shared by tests/test_fullsize_*_gpu.py: built once per session (64 s) ----
+@pytest.fixture(scope="session")
+def fullsize_modules(cuda, hip_lib):
+    import gc
+    import time
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fullsize_cases as fc
+    from aether_amd.transformer import AetherTransformer3D
+    from aether_amd.vae import AetherVAE
+    t0 = time.perf_counter()
+    oracle, cfg = fc.build_oracle_dit()
+    sd = fc.bf16_state_dict(oracle)
+    del oracle
+    gc.collect()
+    dit = AetherTransformer3D({k: getattr(cfg, k) for k in cfg.__dataclass_fields__}, device=cuda).load_state_dict(sd)
+    del sd
+    gc.collect()
+    vae = AetherVAE(dict(fc.VAE_KW), device=cuda).load_state_dict(fc.bf16_state_dict(fc.build_oracle_vae()))
+    vae.enable_tiling()
+    vae.enable_slicing()
+    print(f"\n[fullsize] {cfg.num_layers}-block seeded weights built on the host and packed on the device in {time.perf_counter() - t0:.0f} s")
+    return dit, vae

@@ -36,28 +36,13 @@ def _load(name):
 
 
 @pytest.fixture(scope="module")
-def native_dit(cuda, hip_lib):
-    from aether_amd.transformer import AetherTransformer3D
-    t0 = time.perf_counter()
-    oracle, cfg = fc.build_oracle_dit()
-    sd = fc.bf16_state_dict(oracle)
-    del oracle
-    gc.collect()
-    native = AetherTransformer3D({k: getattr(cfg, k) for k in cfg.__dataclass_fields__}, device=cuda).load_state_dict(sd)
-    del sd
-    gc.collect()
-    print(f"\n[fullsize] {cfg.num_layers}-block seeded weights built on the host and packed on the device in {time.perf_counter() - t0:.0f} s")
-    return native
+def native_dit(fullsize_modules):
+    return fullsize_modules[0]
 
 
 @pytest.fixture(scope="module")
-def native_vae(cuda, hip_lib):
-    from aether_amd.vae import AetherVAE
-    oracle = fc.build_oracle_vae()
-    native = AetherVAE(dict(fc.VAE_KW), device=cuda).load_state_dict(fc.bf16_state_dict(oracle))
-    native.enable_tiling()
-    native.enable_slicing()
-    return native
+def native_vae(fullsize_modules):
+    return fullsize_modules[1]
 
 
 def test_dit_42_blocks_full_sequence(cuda, native_dit):

@@ -15,8 +15,7 @@ AETHER_EPI_BIAS = 0
 AETHER_EPI_BIAS_GELU = 1
 AETHER_EPI_BIAS_GATE_RES = 2
 AETHER_GEMM_WIDE_STORE = 1
-AETHER_GEMM_SPLIT_LONE_TAIL = 2   # a launch of 64..128 tiles with K >= 2048 also splits its K loop (fused-qkv remainder only)
-AETHER_DIT_FUSE_QKV_PREP = 65536  # aether_dit_forward: q/k norm + RoPE + V transpose in the qkv GEMM's epilogue
+AETHER_ATTN_ROW_STORE = 64    # attention: whole 128-byte output rows through LDS (see include/aether_hip.h)
 AETHER_ATTN_EXACT_MAX = 32    # attention: conservative path only (true-maximum shift from tile 0, a-posteriori check per tile)
 AETHER_VAE_TWO_LANES = 256    # VAE plan: tile batches of two on two streams (see include/aether_hip.h)
 AETHER_CONV_TAP_REUSE = 128   # conv: K order is (dt, dh, channel block, dw) -> the tap-reuse kernel may be used
@@ -55,9 +54,6 @@ SIGNATURES = {
     "aether_patchify": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "aether_unpatchify": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "aether_qk_norm_rope": (_i, [_vp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _f, _fp, _fp, _f, _vp, _vp, _vp, _i, _vp]),
-    "aether_qk_norm_rope_tail": (_i, [_vp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _f, _fp, _fp, _f, _vp, _vp, _vp, _i, _i, _vp]),
-    "aether_vt_pad_zero": (_i, [_vp, _i, _i, _i, _vp]),
-    "aether_gemm_qkv_prep": (_i, [_vp, _i, _vp, _i, _fp, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _f, _fp, _fp, _f, _vp, _vp, _vp, _i, _i, _vp]),
     "aether_flash_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "aether_dpm_step": (_i, [_vp, _i, _f, _vp, _fp, _vp, _f, _f, _f, _f, _f, _f, _f, _fp, _fp, _vp, C.c_long, _vp]),
     "aether_conv_gemm_bf16": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _fp, _vp, _i, _fp, _sz, _i, _vp]),

@@ -33,16 +33,6 @@ const char* const kRequired[] = {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// Row tiles (of 256 rows) the fused qkv GEMM takes at B = 1: its epilogue has no split-K form, so a launch whose last round of 256
-// workgroups would be mostly empty (59 x 36 = 2124 tiles = 8.3 rounds) stops at the largest row-tile count that fills its rounds to
-// >= 95 % (56 x 36 = 2016 = 7.9 rounds); the remaining rows go through the plain GEMM (with its split-K tail) + aether_qk_norm_rope_tail.
-inline int fused_row_tiles(int tm, int tiles_n) {
-    auto fill = [&](int t) { const long n = (long)t * tiles_n, r = (n + 255) / 256; return (double)n / (double)(r * 256); };
-    if (fill(tm) >= 0.95) return tm;
-    for (int t = tm - 1; t >= std::max(1, tm - 8); --t)
-        if (fill(t) >= 0.95) return t;
-    return tm;
-}
 constexpr size_t kSplitKBytes = (size_t)256 * 256 * 256 * sizeof(float);   // fp32 partial tiles of a GEMM tail launch (<= 256 workgroups)
 
 struct Plan {
@@ -245,39 +235,17 @@ extern "C" int aether_dit_forward(AetherDit* h, const void* hidden, const void* 
     // softmax scale 1/sqrt(64) and log2(e) folded into Q in fp32 before its single rounding to bf16: scores arrive in
     // the log2 domain.
     const float q_scale = 0.125f * 1.4426950408889634f;
-    // q/k norm + RoPE + V^T as the qkv GEMM's epilogue (AETHER_DIT_FUSE_QKV_PREP); needs the 256-wide head grouping
-    const bool fuse_qkv = (fl & AETHER_DIT_FUSE_QKV_PREP) != 0 && D % 256 == 0;
-    int rows_f = M;
-    if (fuse_qkv) {
-        if (B == 1) rows_f = std::min(M, fused_row_tiles((M + 255) / 256, 3 * D / 256) * 256);
-        if (rows_f == M) AE_TRY(aether_vt_pad_zero(vt, B * c.num_heads * 64, S, p.Spad, stream));    // (a tail launch zeroes the pads itself)
-    }
     for (int i = 0; i < L; ++i) {
         const float* m1 = mod + (size_t)i * 12 * D;  // shift, scale, gate, enc_shift, enc_scale, enc_gate
         const float* m2 = m1 + 6 * D;
         AE_RUN(AETHER_PROF_LN, aether_layernorm_modulate(x, D, xn, D, M, D, c.norm_eps, Wf("ln1_w") + (size_t)i * D, Wf("ln1_b") + (size_t)i * D,
                                          m1, m1 + D, m1 + 3 * D, m1 + 4 * D, p.Nmod, S, Nt, stream));
-        if (fuse_qkv) {
-            // q/k norm + RoPE + V^T in the epilogue of the qkv projection (the leading `rows_f` rows; any remainder un-fused)
-            auto fused = [&]() -> int {
-                int rc = aether_gemm_qkv_prep(xn, D, W_("qkv_w") + (size_t)i * 3 * D * D * 2, D, Wf("qkv_b") + (size_t)i * 3 * D, rows_f, c.num_heads, D, S, Nt,
-                                              Wf("qn_w") + i * 64, Wf("qn_b") + i * 64, Wf("kn_w") + i * 64, Wf("kn_b") + i * 64, c.qk_norm_eps, rope_cos,
-                                              rope_sin, q_scale, qh, kh, vt, p.Spad, fl, stream);
-                if (rc || rows_f == M) return rc;
-                return aether_gemm_bf16(xn + (size_t)rows_f * D * 2, D, W_("qkv_w") + (size_t)i * 3 * D * D * 2, D, qkv + (size_t)rows_f * 3 * D * 2, 3 * D,
-                                        M - rows_f, 3 * D, D, Wf("qkv_b") + (size_t)i * 3 * D, AETHER_EPI_BIAS, nullptr, 0, nullptr, nullptr, 0, 0, 0, skws,
-                                        kSplitKBytes, fl | AETHER_GEMM_SPLIT_LONE_TAIL, stream);
-            };
-            AE_RUN(AETHER_PROF_GEMM_QKV, fused());
-            if (rows_f < M)
-                AE_RUN(AETHER_PROF_QKROPE, aether_qk_norm_rope_tail(qkv, B, S, c.num_heads, Nt, Wf("qn_w") + i * 64, Wf("qn_b") + i * 64, Wf("kn_w") + i * 64,
-                                           Wf("kn_b") + i * 64, c.qk_norm_eps, rope_cos, rope_sin, q_scale, qh, kh, vt, p.Spad, rows_f, stream));
-        } else {
-            AE_RUN(AETHER_PROF_GEMM_QKV, aether_gemm_bf16(xn, D, W_("qkv_w") + (size_t)i * 3 * D * D * 2, D, qkv, 3 * D, M, 3 * D, D,
-                                    Wf("qkv_b") + (size_t)i * 3 * D, AETHER_EPI_BIAS, nullptr, 0, nullptr, nullptr, 0, 0, 0, skws, kSplitKBytes, fl, stream));
-            AE_RUN(AETHER_PROF_QKROPE, aether_qk_norm_rope(qkv, B, S, c.num_heads, Nt, Wf("qn_w") + i * 64, Wf("qn_b") + i * 64, Wf("kn_w") + i * 64,
-                                       Wf("kn_b") + i * 64, c.qk_norm_eps, rope_cos, rope_sin, q_scale, qh, kh, vt, p.Spad, stream));
-        }
+        AE_RUN(AETHER_PROF_GEMM_QKV, aether_gemm_bf16(xn, D, W_("qkv_w") + (size_t)i * 3 * D * D * 2, D, qkv, 3 * D, M, 3 * D, D,
+                                Wf("qkv_b") + (size_t)i * 3 * D, AETHER_EPI_BIAS, nullptr, 0, nullptr, nullptr, 0, 0, 0, skws, kSplitKBytes, fl, stream));
+        // (q/k norm + RoPE + V^T as the qkv GEMM's EPILOGUE was built and measured in round 3: parity green, net 0 +- 0.5 ms per step — 8 waves
+        // x 256 registers leave the epilogue nothing to hide its table fetches behind — and retired in round 4: profiles/r03_fused_qkv_epilogue.txt)
+        AE_RUN(AETHER_PROF_QKROPE, aether_qk_norm_rope(qkv, B, S, c.num_heads, Nt, Wf("qn_w") + i * 64, Wf("qn_b") + i * 64, Wf("kn_w") + i * 64,
+                                   Wf("kn_b") + i * 64, c.qk_norm_eps, rope_cos, rope_sin, q_scale, qh, kh, vt, p.Spad, stream));
         AE_RUN(AETHER_PROF_ATTN, aether_flash_attn_fwd(qh, kh, vt, attn, B, c.num_heads, S, p.Spad, fl, stream));
         AE_RUN(AETHER_PROF_GEMM_O, aether_gemm_bf16(attn, D, W_("o_w") + (size_t)i * D * D * 2, D, x, D, M, D, D, Wf("o_b") + (size_t)i * D,
                                 AETHER_EPI_BIAS_GATE_RES, x, D, m1 + 2 * D, m1 + 5 * D, p.Nmod, S, Nt, skws, kSplitKBytes, fl, stream));

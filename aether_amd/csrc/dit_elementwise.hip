@@ -195,7 +195,6 @@ struct QkArgs {
     const float* qn_w; const float* qn_b; const float* kn_w; const float* kn_b; float eps;
     const float* cos_t; const float* sin_t; float q_scale;
     bf16_t* Qh; bf16_t* Kh; unsigned short* Vt;
-    int tile_first;       // first 64-token tile of this launch (the fused qkv GEMM epilogue may have done the tiles before it)
 };
 
 // LayerNorm(64) of one head row spread over 8 lanes (8 values each) + affine + RoPE (adjacent pairs) + scale, rounded to bf16;
@@ -232,7 +231,7 @@ __global__ __launch_bounds__(256) void qkv_prepare_kernel(QkArgs p) {
     // head fastest in the grid: the workgroups running together cover the same 64 token rows across all heads, i.e. whole
     // contiguous 18 KiB rows of the projection between them
     const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
-    const int tile_idx = blockIdx.y + p.tile_first;
+    const int tile_idx = blockIdx.y;
     const int s0 = tile_idx * 64;
     const int HD = p.H * 64;
     const int tid = threadIdx.x;
@@ -367,37 +366,8 @@ extern "C" int aether_qk_norm_rope(const void* qkv, int B, int S, int H, int n_t
     if (n_text < S && (!cos_t || !sin_t)) return aether_set_error(AETHER_ERR_ARG, "qk_norm_rope: rope tables required");
     if (Spad % 64 != 0 || Spad < S) return aether_set_error(AETHER_ERR_SHAPE, "qk_norm_rope: Spad must be roundup(S,64)");
     QkArgs p{(const bf16_t*)qkv, S, H, n_text, Spad, qn_w, qn_b, kn_w, kn_b, eps, cos_t, sin_t, q_scale, (bf16_t*)Qh, (bf16_t*)Kh,
-             (unsigned short*)Vt, 0};
+             (unsigned short*)Vt};
     hipLaunchKernelGGL(qkv_prepare_kernel, dim3(B * H, Spad / 64), dim3(256), 0, AE_STREAM, p);
     return aether_check_launch("qkv_prepare");
 }
 
-// The same for the tokens s >= first_token (a multiple of 64) only: the tail rows of a forward whose leading rows were prepared in the
-// epilogue of the fused qkv projection (aether_gemm_qkv_prep).  Covers the ragged last tile, i.e. also zeroes the pad columns of V^T.
-extern "C" int aether_qk_norm_rope_tail(const void* qkv, int B, int S, int H, int n_text, const float* qn_w, const float* qn_b,
-                                        const float* kn_w, const float* kn_b, float eps, const float* cos_t, const float* sin_t,
-                                        float q_scale, void* Qh, void* Kh, void* Vt, int Spad, int first_token, void* stream) {
-    if (!qkv || !Qh || !Kh || !Vt || !qn_w || !qn_b || !kn_w || !kn_b) return aether_set_error(AETHER_ERR_ARG, "qk_norm_rope_tail: null pointer");
-    if (B <= 0 || S <= 0 || H <= 0 || n_text < 0 || n_text > S) return aether_set_error(AETHER_ERR_SHAPE, "qk_norm_rope_tail: bad shape");
-    if (n_text < S && (!cos_t || !sin_t)) return aether_set_error(AETHER_ERR_ARG, "qk_norm_rope_tail: rope tables required");
-    if (Spad % 64 != 0 || Spad < S || first_token < 0 || first_token % 64 != 0 || first_token >= Spad)
-        return aether_set_error(AETHER_ERR_SHAPE, "qk_norm_rope_tail: Spad must be roundup(S,64), first_token a multiple of 64 below it");
-    QkArgs p{(const bf16_t*)qkv, S, H, n_text, Spad, qn_w, qn_b, kn_w, kn_b, eps, cos_t, sin_t, q_scale, (bf16_t*)Qh, (bf16_t*)Kh,
-             (unsigned short*)Vt, first_token / 64};
-    hipLaunchKernelGGL(qkv_prepare_kernel, dim3(B * H, (Spad - first_token) / 64), dim3(256), 0, AE_STREAM, p);
-    return aether_check_launch("qkv_prepare (tail)");
-}
-
-// zero the pad columns [S, Spad) of V^T [rows = B*H*64][Spad] (the attention kernel multiplies them by p = 0: they must be finite)
-__global__ void vt_pad_zero_kernel(unsigned short* vt, int rows, int S, int Spad) {
-    const int npad = Spad - S;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)rows * npad; i += (long)gridDim.x * blockDim.x)
-        vt[(i / npad) * (long)Spad + S + (i % npad)] = 0;
-}
-extern "C" int aether_vt_pad_zero(void* Vt, int rows, int S, int Spad, void* stream) {
-    if (!Vt || rows <= 0 || S <= 0 || Spad < S) return aether_set_error(AETHER_ERR_ARG, "vt_pad_zero: bad arguments");
-    if (Spad == S) return AETHER_OK;
-    const long total = (long)rows * (Spad - S);
-    hipLaunchKernelGGL(vt_pad_zero_kernel, dim3((unsigned)std::min<long>(1024, (total + 255) / 256)), dim3(256), 0, AE_STREAM, (unsigned short*)Vt, rows, S, Spad);
-    return aether_check_launch("vt_pad_zero");
-}

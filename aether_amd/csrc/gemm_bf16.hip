@@ -107,10 +107,7 @@ extern "C" int aether_gemm_bf16(const void* A, int lda, const void* W, int ldw, 
     const int full = tiles / NCU * NCU, rest = tiles - full;
     int ks = (rest > 0 && rest <= NCU / 2) ? NCU / rest : 1;
     if (ks > nk / 4) ks = nk / 4;
-    // (a launch of fewer than 256 tiles splits too when it would leave most CUs idle for a whole tile time and K is long enough to share:
-    // the 108-tile remainder of the fused qkv projection, aether_dit_forward)
-    const bool lone_tail = (flags & AETHER_GEMM_SPLIT_LONE_TAIL) != 0 && full == 0 && rest >= 64 && nk >= 32;
-    if (ks < 2 || splitk_ws == nullptr || (full == 0 && !lone_tail) || (((uintptr_t)splitk_ws) & 15) ||
+    if (ks < 2 || splitk_ws == nullptr || full == 0 || (((uintptr_t)splitk_ws) & 15) ||
         (size_t)ks * rest * 256 * 256 * sizeof(float) > splitk_ws_bytes)
         ks = 1;
     p.ntile_launch = (ks > 1) ? full : tiles;
@@ -126,12 +123,10 @@ extern "C" int aether_gemm_bf16(const void* A, int lda, const void* W, int ldw, 
         case EPI_BIAS_GELU: LAUNCH(EPI_BIAS_GELU); break;   \
         default: LAUNCH(EPI_BIAS_GATE_RES); break;          \
     }
-    if (!(ks > 1 && full == 0)) {
-        p.ksplit = 1;
-        LAUNCH_EPI();
-        rc = aether_check_launch("gemm_bf16");
-        if (rc || ks == 1) return rc;
-    }
+    p.ksplit = 1;
+    LAUNCH_EPI();
+    rc = aether_check_launch("gemm_bf16");
+    if (rc || ks == 1) return rc;
     p.tile_base = full; p.ntile_launch = rest; p.ksplit = ks; p.part = splitk_ws; p.part_tiled = 1;
     LAUNCH_EPI();
     rc = aether_check_launch("gemm_bf16 (tail)");
@@ -145,40 +140,4 @@ extern "C" int aether_gemm_bf16(const void* A, int lda, const void* W, int ldw, 
 #undef LAUNCH_EPI
 #undef LAUNCH
     return aether_check_launch("gemm_tail_finalize");
-}
-
-
-// Fused qkv projection + attention-operand preparation: C is never written; the epilogue (EPI_QKV_PREP, gemm_kernel.hpp) turns the
-// accumulators of q / k / v head tiles straight into Qh, Kh [B,H,S,64] and V^T [B,H,64,Spad] — what aether_gemm_bf16 followed by
-// aether_qk_norm_rope produce (diffusers' to_q / to_k / to_v, norm_q / norm_k, apply_rotary_emb in CogVideoXAttnProcessor2_0; reference call
-// aether/pipelines/aetherv1_pipeline_cogvideox.py:865-875).  One workgroup per 256x256 tile, no split-K tail (the caller keeps the last,
-// partly filled round out of this launch: see aether_dit_forward).
-extern "C" int aether_gemm_qkv_prep(const void* A, int lda, const void* W, int ldw, const float* bias, int M, int heads, int K, int S, int n_text,
-                                    const float* qn_w, const float* qn_b, const float* kn_w, const float* kn_b, float eps, const float* cos_t,
-                                    const float* sin_t, float q_scale, void* Qh, void* Kh, void* Vt, int Spad, int flags, void* stream) {
-    const int N = 3 * heads * 64;
-    if (!A || !W || !Qh || !Kh || !Vt || !qn_w || !qn_b || !kn_w || !kn_b) return aether_set_error(AETHER_ERR_ARG, "gemm_qkv_prep: null pointer");
-    if (M <= 0 || heads <= 0 || K <= 0 || S <= 0 || M % S != 0 && M > S) return aether_set_error(AETHER_ERR_SHAPE, "gemm_qkv_prep: M must be rows of whole batch items (or the leading rows of one)");
-    if (K % GEMM_BK != 0 || (heads * 64) % 256 != 0 || (lda % 8) || (ldw % 8)) return aether_set_error(AETHER_ERR_SHAPE, "gemm_qkv_prep: K % 64, heads % 4, lda % 8, ldw % 8 must be 0");
-    if (n_text < 0 || n_text > S || (n_text < S && (!cos_t || !sin_t))) return aether_set_error(AETHER_ERR_ARG, "gemm_qkv_prep: rope tables required");
-    if (Spad % 64 != 0 || Spad < S) return aether_set_error(AETHER_ERR_SHAPE, "gemm_qkv_prep: Spad must be roundup(S,64)");
-    if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)bias | (uintptr_t)Qh | (uintptr_t)Kh | (uintptr_t)Vt | (uintptr_t)qn_w | (uintptr_t)qn_b | (uintptr_t)kn_w |
-         (uintptr_t)kn_b | (uintptr_t)cos_t | (uintptr_t)sin_t) & 15)
-        return aether_set_error(AETHER_ERR_ALIGN, "gemm_qkv_prep: pointers must be 16-byte aligned");
-    if ((size_t)M * (size_t)lda * 2 >= (1ull << 32) || (size_t)N * (size_t)ldw * 2 >= (1ull << 32))
-        return aether_set_error(AETHER_ERR_SHAPE, "gemm_qkv_prep: operand exceeds the 4 GiB a buffer descriptor can address");
-    GemmArgs p = {};
-    p.A = (const bf16_t*)A; p.lda = lda; p.W = (const bf16_t*)W; p.ldw = ldw; p.C = nullptr; p.ldc = 0;
-    p.M = M; p.N = N; p.K = K; p.bias = bias;
-    p.rows_per_batch = S; p.n_text = n_text;
-    p.tiles_m = (M + 255) / 256; p.tiles_n = N / 256;
-    p.a_bytes = (unsigned)(((size_t)(M - 1) * lda + K) * 2);
-    p.w_bytes = (unsigned)(((size_t)(N - 1) * ldw + K) * 2);
-    p.ksplit = 1; p.tile_base = 0; p.ntile_launch = p.tiles_m * p.tiles_n;
-    p.qn_w = qn_w; p.qn_b = qn_b; p.kn_w = kn_w; p.kn_b = kn_b; p.qk_eps = eps; p.cos_t = cos_t; p.sin_t = sin_t; p.q_scale = q_scale;
-    p.Qh = (bf16_t*)Qh; p.Kh = (bf16_t*)Kh; p.Vt = (unsigned short*)Vt; p.heads = heads; p.Spad = Spad;
-    const dim3 grid(p.ntile_launch), block(512);
-    if (flags & AETHER_GEMM_WIDE_STORE) hipLaunchKernelGGL((gemm_bf16_kernel<2, 4, 4, 2, EPI_QKV_PREP, true, false>), grid, block, 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<2, 4, 4, 2, EPI_QKV_PREP, false, false>), grid, block, 0, (hipStream_t)stream, p);
-    return aether_check_launch("gemm_qkv_prep");
 }

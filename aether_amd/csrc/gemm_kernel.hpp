@@ -20,8 +20,7 @@
 
 namespace aether {
 
-enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_GATE_RES = 2,
-       EPI_QKV_PREP = 3 };   // fused qkv projection: q/k LayerNorm(64) + 3-D RoPE (+ soft-max scale on q) -> head-major Qh / Kh, V -> V^T
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_GATE_RES = 2 };
 
 struct GemmArgs {
     const bf16_t* A; int lda;
@@ -49,10 +48,6 @@ struct GemmArgs {
     int tile_base, ntile_launch;
     int part_tiled;             // split-K partials stored tile-major [slice][tile - tile_base][BM][BN] instead of [slice][M][N]
     unsigned a_bytes, w_bytes;  // extents of A and W in bytes (< 4 GiB): bounds of the buffer descriptors the LDS-DMA goes through
-    // EPI_QKV_PREP only (N = 3 * heads * 64; rows_per_batch = S tokens per batch item; n_text rows carry no rotary embedding):
-    const float* qn_w; const float* qn_b; const float* kn_w; const float* kn_b; float qk_eps;
-    const float* cos_t; const float* sin_t; float q_scale;
-    bf16_t* Qh; bf16_t* Kh; unsigned short* Vt; int heads, Spad;
 };
 
 constexpr int GEMM_BK = 64;
@@ -72,138 +67,7 @@ AE_DEV void gemm_tile_coords(int wgid, int tiles_m, int tiles_n, int& tile_m, in
 // ---- fused epilogue of one output tile (shared by the one-tile-per-workgroup kernel below and the persistent kernel) -------------------
 // acc[mt][nt][r] = C[m][n], m = m0 + (wm*MT + mt)*32 + l32,  n = n0 + (wn*NT + nt)*32 + 8*(r>>2) + 4*hi + (r&3)
 template <int WM, int WN, int MT, int NT, int EPI, bool WIDE_STORE>
-AE_DEV void gemm_epilogue(const GemmArgs& p, const f32x16 (&acc)[MT][NT], int m0, int n0, int wm, int wn, int l32, int hi, char* lds = nullptr) {
-    if constexpr (EPI == EPI_QKV_PREP) {
-        // The wave's 64 columns are ONE head of q, k or v (NT * 32 == 64, tiles start on multiples of 256 columns).  What aether_qk_norm_rope
-        // does in a pass of its own happens here on the accumulators: the projection is rounded to bf16 exactly as the plain epilogue
-        // would store it, then — q, k — LayerNorm over the head's 64 values (32 in this lane, 32 in lane ^ 32), affine, rotary embedding of
-        // the video rows (adjacent pairs: both elements of a pair sit in one lane), soft-max scale on q, one rounding, 16-byte stores into
-        // the head-major [B, H, S, 64] layout; — v — transposed through the wave's own 16 KiB of the (now idle) operand buffers in LDS and
-        // written to V^T [B, H, 64, Spad] as 16-byte pieces (after the main loop's last barrier no wave reads or DMA-writes LDS any more).
-        static_assert(NT * 32 == 64, "one head per wave");
-        const int D = p.heads * 64;
-        const int ncol0 = n0 + wn * 64;
-        if (ncol0 >= p.N) return;                                   // wave-uniform
-        const int part = ncol0 / D, head = (ncol0 - part * D) >> 6;
-        const int S = p.rows_per_batch;
-        f32x4 bv[NT][4];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) bv[nt][g] = p.bias ? *(const f32x4*)(p.bias + ncol0 + nt * 32 + 8 * g + 4 * hi) : f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* nw = part == 0 ? p.qn_w : p.kn_w;
-        const float* nb = part == 0 ? p.qn_b : p.kn_b;
-        const float sc = part == 0 ? p.q_scale : 1.0f;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int m = m0 + (wm * MT + mt) * 32 + l32;
-            const bool m_ok = m < p.M;
-            const int mm = m_ok ? m : p.M - 1;
-            const int b = mm / S, s = mm - b * S;
-            float v[NT][16];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[nt][4 * g + c] = bf16_bits_to_f32(f32_to_bf16_bits(acc[mt][nt][4 * g + c] + bv[nt][g][c]));
-            if (part == 2) {                                        // wave-uniform: this head's values go into the wave's 16 KiB of LDS, [d][token]
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int d = nt * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
-                        *(unsigned short*)(lds + d * (MT * 64) + (mt * 32 + l32) * 2) = f32_to_bf16_bits(v[nt][e]);
-                    }
-                continue;
-            }
-            float sum = 0.f;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) sum += v[nt][e];
-            sum += __shfl_xor(sum, 32, 64);
-            const float mean = sum * (1.0f / 64.0f);
-            float sq = 0.f;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) { const float dlt = v[nt][e] - mean; sq += dlt * dlt; }
-            sq += __shfl_xor(sq, 32, 64);
-            const float rstd = rsqrtf(sq * (1.0f / 64.0f) + p.qk_eps);
-            const int vtok = s - p.n_text;
-            const bool rope = vtok >= 0 && p.cos_t != nullptr;
-            bf16_t* orow = (part == 0 ? p.Qh : p.Kh) + ((size_t)(b * p.heads + head) * S + s) * 64;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                unsigned pk[4][2];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int col = nt * 32 + 8 * g + 4 * hi;
-                    const f32x4 w4 = *(const f32x4*)(nw + col), b4 = *(const f32x4*)(nb + col);
-                    float o[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) o[c] = (v[nt][4 * g + c] - mean) * rstd * w4[c] + b4[c];
-                    if (rope) {
-                        const f32x4 cs = *(const f32x4*)(p.cos_t + (size_t)vtok * 64 + col), sn = *(const f32x4*)(p.sin_t + (size_t)vtok * 64 + col);
-#pragma unroll
-                        for (int c = 0; c < 4; c += 2) {
-                            const float x0 = o[c], x1 = o[c + 1];
-                            o[c] = x0 * cs[c] - x1 * sn[c];
-                            o[c + 1] = x1 * cs[c + 1] + x0 * sn[c + 1];
-                        }
-                    }
-                    pk[g][0] = pack_bf16x2(o[0] * sc, o[1] * sc);
-                    pk[g][1] = pack_bf16x2(o[2] * sc, o[3] * sc);
-                }
-                if (WIDE_STORE) {
-#pragma unroll
-                    for (int g = 0; g < 4; g += 2) {
-                        auto r0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
-                        auto r1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
-                        if (m_ok) *(uint4*)(orow + nt * 32 + 8 * g + 8 * hi) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
-                    }
-                } else {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        if (m_ok) *(uint2*)(orow + nt * 32 + 8 * g + 4 * hi) = make_uint2(pk[g][0], pk[g][1]);
-                }
-            }
-        }
-        if (part == 2) {
-            // V^T write-out: 16-byte pieces = 8 consecutive tokens of one d (a transposed 2-byte store per value costs 128 store
-            // instructions per lane and tile — store issue, not bandwidth, made V tiles 45 % slower than q / k tiles).  16 lanes cover one d row
-            // of the wave's 128 tokens: 256 contiguous bytes per d in LDS and in V^T.  Pieces that straddle the end of the rows, a batch
-            // boundary, or whose first token is not a multiple of 8 in its batch item (S % 8 != 0, b > 0) fall back to narrower stores.
-            const int lane = 32 * hi + l32;
-            constexpr int PIECES = MT * 32 / 8;                     // 16-byte pieces per d row (16)
-#pragma unroll
-            for (int j = 0; j < 64 * PIECES / 64; ++j) {
-                const int q = j * 64 + lane;
-                const int d = q / PIECES, t8 = q - d * PIECES;
-                const uint4 w = *(const uint4*)(lds + d * (MT * 64) + t8 * 16);
-                const int m = m0 + wm * (MT * 32) + t8 * 8;
-                if (m >= p.M) continue;
-                const int b = m / S, s = m - b * S;
-                unsigned short* dst = p.Vt + ((size_t)(b * p.heads + head) * 64 + d) * p.Spad + s;
-                const bool whole = m + 7 < p.M && s + 7 < S;
-                if (whole && (s & 7) == 0) *(uint4*)dst = w;
-                else if (whole && (s & 3) == 0) { *(uint2*)dst = make_uint2(w.x, w.y); *(uint2*)(dst + 4) = make_uint2(w.z, w.w); }
-                else {
-                    const unsigned wd[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int me = m + e;
-                        if (me < p.M) {
-                            const int be = me / S, se = me - be * S;
-                            p.Vt[((size_t)(be * p.heads + head) * 64 + d) * p.Spad + se] = (unsigned short)(wd[e >> 1] >> (16 * (e & 1)));
-                        }
-                    }
-                }
-            }
-        }
-        return;
-    }
+AE_DEV void gemm_epilogue(const GemmArgs& p, const f32x16 (&acc)[MT][NT], int m0, int n0, int wm, int wn, int l32, int hi) {
     // Every operand of the epilogue is fetched BEFORE it is used, in batches: the bias of the wave's column groups once, then per
     // 32-row block its gate vectors and residual rows (16 loads in flight).  (Round 1 issued each of the 12 loads of a 32x32
     // sub-tile behind its own branch, every one followed by s_waitcnt vmcnt(0): 96 dependent round trips ≈ 15 µs per tile — 18 %
@@ -541,7 +405,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
         }
         return;
     }
-    gemm_epilogue<WM, WN, MT, NT, EPI, WIDE_STORE>(p, acc, m0, n0, wm, wn, l32, hi, smem + wave * (MT * 32 * 64 * 2));
+    gemm_epilogue<WM, WN, MT, NT, EPI, WIDE_STORE>(p, acc, m0, n0, wm, wn, l32, hi);
 }
 
 }  // namespace aether

@@ -112,27 +112,6 @@ def qk_norm_rope(qkv, H, n_text, qn_w, qn_b, kn_w, kn_b, eps, cos, sin, q_scale)
     return Qh, Kh, Vt
 
 
-def gemm_qkv_prep(A, W, bias, H, S, n_text, qn_w, qn_b, kn_w, kn_b, eps, cos, sin, q_scale, flags=1, rows=None):
-    """Fused qkv projection + q/k norm + RoPE + V transpose (aether_gemm_qkv_prep): A bf16 [B*S, K], W bf16 [3*H*64, K] ->
-    (Qh [B,H,S,64], Kh [B,H,S,64], Vt [B,H,64,Spad]); `rows` < B*S prepares only the leading rows (B = 1).  The pad columns of Vt are
-    zeroed here (aether_vt_pad_zero) so the result compares with `qk_norm_rope` directly."""
-    _need_cuda(A, W)
-    M, K = A.shape
-    B = M // S
-    assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and A.is_contiguous() and W.is_contiguous() and W.shape == (3 * H * 64, K)
-    Spad = (S + 63) // 64 * 64
-    Qh = torch.zeros(B, H, S, 64, dtype=torch.bfloat16, device=A.device)
-    Kh = torch.zeros_like(Qh)
-    Vt = torch.full((B, H, 64, Spad), float("nan"), dtype=torch.bfloat16, device=A.device)
-    lib = _lib.load()
-    _lib.check(lib.aether_vt_pad_zero(_lib.ptr(Vt), B * H * 64, S, Spad, _lib.current_stream()), "aether_vt_pad_zero")
-    rc = lib.aether_gemm_qkv_prep(_lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(bias), M if rows is None else rows, H, K, S, n_text, _lib.ptr(qn_w), _lib.ptr(qn_b),
-                                  _lib.ptr(kn_w), _lib.ptr(kn_b), float(eps), _lib.ptr(cos), _lib.ptr(sin), float(q_scale), _lib.ptr(Qh), _lib.ptr(Kh),
-                                  _lib.ptr(Vt), Spad, flags, _lib.current_stream())
-    _lib.check(rc, "aether_gemm_qkv_prep")
-    return Qh, Kh, Vt
-
-
 def flash_attn_fwd(Qh, Kh, Vt, flags=0):
     """Qh,Kh [B,H,S,64] (softmax scale x log2(e) folded into Qh: _lib.ATTN_Q_SCALE), Vt [B,H,64,Spad] -> O [B,S,H*64].
     flags: AETHER_GEMM_WIDE_STORE | AETHER_ATTN_EXACT_MAX (the conservative path alone)."""

@@ -208,9 +208,9 @@ class AetherV1PipelineCogVideoX(_PipelineBase):
     # Extension: run the element-wise tail of every denoise step (P:877-916) as one HIP kernel (aether_dpm_step) when the scheduler is this
     # repo's CogVideoXDPMScheduler on an MI355X.  Bit-identical to the PyTorch sequence; False keeps the reference's op-by-op form.
     fuse_step_tail = True
-    # Extension: enqueue the two final VAE decodes (rgb, disparity: P:931,936) on two HIP streams so their small launches fill each other's
-    # gaps (measured −8.8 % for the pair at 41 x 480 x 720, profiles/r03_decode_pair.json); bit-identical outputs, one more VAE workspace.
-    # False = the reference's sequential calls.
+    # Extension: hand the two final VAE decodes (rgb, disparity: P:931,936) to `AetherVAE.decode_pair` — two calls in a row under the two-lane
+    # launch plan (each decode runs its tile batches on two streams); two HIP streams over a twin context (one more VAE workspace) without it.
+    # Bit-identical outputs.  False = the reference's two `decode_latents` calls.
     decode_concurrently = True
 
     def __init__(self, tokenizer, text_encoder, vae, scheduler, transformer, empty_prompt_embeds: Optional[torch.Tensor] = None):
@@ -549,7 +549,7 @@ class AetherV1PipelineCogVideoX(_PipelineBase):
             rgb_decoded, disparity_decoded = self._gather_pair(
                 self.decode_latents(rgb_latents if self._cfg_rank == 0 else disparity_latents)).split(1)
         elif self.decode_concurrently and hasattr(self.vae, "decode_pair") and latents.is_cuda:
-            # the two decodes of P:931,936 on two HIP streams (aether_amd.vae.AetherVAE.decode_pair): same kernels, bit-identical results
+            # the two decodes of P:931,936 through aether_amd.vae.AetherVAE.decode_pair: same kernels, bit-identical results
             inv = 1 / self.vae_scaling_factor_image
             try:
                 rgb_decoded, disparity_decoded = self.vae.decode_pair(inv * rgb_latents.permute(0, 2, 1, 3, 4), inv * disparity_latents.permute(0, 2, 1, 3, 4))

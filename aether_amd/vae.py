@@ -728,10 +728,15 @@ class AetherVAE:
 
     @torch.no_grad()
     def decode_pair(self, z_a: torch.Tensor, z_b: torch.Tensor):
-        """`(decode(z_a).sample, decode(z_b).sample)` with the two decodes enqueued on two HIP streams.  A decode is ~4 700 launches, a
-        quarter of them (the 512-channel levels at latent resolution, GroupNorm statistics, split-K finalizes) too small to fill 256 CUs:
-        two independent decodes fill each other's gaps.  Same kernels, same order within each decode: results are bit-identical to the
-        sequential calls (tests/test_vae_gpu.py::test_decode_pair_is_bit_identical).  Costs a second workspace (28.8 GB at 41 x 480 x 720)."""
+        """`(decode(z_a).sample, decode(z_b).sample)` — the pipeline's two final decodes (rgb and disparity latents, P:931,936).
+        With the two-lane launch plan (AETHER_VAE_TWO_LANES, the default) every decode already runs its tile batches on two streams, and the pair is
+        simply the two calls one after the other: 0.768 s per pair at 41 x 480 x 720, where two ONE-lane decodes on two streams took 0.765 s and
+        two TWO-lane decodes on two streams (four streams in all) 0.836 s (profiles/r04_vae_lanes_ab.json) — and no second workspace.
+        Without the lanes flag the two decodes are enqueued on two HIP streams over a twin launch context (a second C handle over the same packed
+        weights with a workspace and hipGraphs of its own: + 28.8 GB).  Same kernels, same order within each decode either way: results are
+        bit-identical to the sequential calls (tests/test_vae_gpu.py::test_decode_pair_is_bit_identical)."""
+        if self._flags & _lib.AETHER_VAE_TWO_LANES:
+            return self.decode(z_a).sample, self.decode(z_b).sample
         if getattr(self, "_twin", None) is None:
             self._twin = self._make_twin()
             # a HIGH-PRIORITY stream: HIP gives priority streams hardware queues of their own, whereas a normal pool stream may share the

@@ -170,7 +170,8 @@ def vae_leg(dev, reps=3):
         torch.cuda.synchronize()
         sec = e0.elapsed_time(e1) * 1e-3 / reps
         out[name] = {"seconds": sec, "algorithmic_tflop": tflop, "tflops": tflop / sec, "mfma_frac": tflop / sec / MFMA_PEAK_TFLOPS}
-    # the pipeline's two final decodes (rgb + disparity latents, P:931,936) as it issues them: on two HIP streams (AetherVAE.decode_pair)
+    # the pipeline's two final decodes (rgb + disparity latents, P:931,936) as it issues them (AetherVAE.decode_pair: with the two-lane launch plan
+    # two calls in a row, each with its tile batches on two streams)
     z2 = torch.randn(1, 16, 11, 60, 90, generator=g, device=dev).to(torch.bfloat16)
     for _ in range(3):
         vae.decode_pair(z, z2)
@@ -180,8 +181,8 @@ def vae_leg(dev, reps=3):
         vae.decode_pair(z, z2)
     torch.cuda.synchronize()
     sec = (time.perf_counter() - t0) / reps
-    out["decode_pair_two_streams"] = {"seconds": sec, "algorithmic_tflop": 2 * 369.0, "tflops": 2 * 369.0 / sec, "mfma_frac": 2 * 369.0 / sec / MFMA_PEAK_TFLOPS,
-                                      "note": "both decodes of one pipeline call, enqueued on two HIP streams; bit-identical to sequential calls"}
+    out["decode_pair"] = {"seconds": sec, "algorithmic_tflop": 2 * 369.0, "tflops": 2 * 369.0 / sec, "mfma_frac": 2 * 369.0 / sec / MFMA_PEAK_TFLOPS,
+                                      "note": "both decodes of one pipeline call (two-lane launch plan: tile batches of two on two HIP streams inside each decode)"}
     del vae
     torch.cuda.empty_cache()
     return out
@@ -421,12 +422,20 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # plumbing check of the N > 1 path on a ONE-GPU box (AETHER_BENCH_ONE_DEVICE=1): every rank on cuda:0, exchange over gloo (RCCL refuses
+        # two ranks on one device); never set by the driver — its N > 1 runs are one rank per GPU over RCCL
+        one_dev = os.environ.get("AETHER_BENCH_ONE_DEVICE") == "1"
+        dev_index = 0 if one_dev else local_rank
+        torch.cuda.set_device(dev_index)
+        if one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
     else:
         dist = None
+        dev_index = 0
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", dev_index)
     if args.windows:
         return windows_mode(args, dev, rank, world, dist)
 
@@ -495,7 +504,7 @@ def main():
 
     elapsed, prof = timed(args.warmup, args.steps)          # THE measurement: default flags, exactly --steps steps
     if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
     assert torch.isfinite(state["latents"].float()).all(), "non-finite latents"

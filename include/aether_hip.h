@@ -46,9 +46,6 @@ int aether_check_device(void);
 #define AETHER_EPI_BIAS_GELU 1     /* C = gelu_tanh(A·Wᵀ + bias)                                 */
 #define AETHER_EPI_BIAS_GATE_RES 2 /* C = R + gate[b(m),type(m),:] ⊙ (A·Wᵀ + bias)               */
 #define AETHER_GEMM_WIDE_STORE 1   /* flags bit: 16-byte stores through a half-wave exchange      */
-#define AETHER_GEMM_SPLIT_LONE_TAIL 2 /* flags bit 1: a launch of 64..128 tiles (less than ONE round of 256) with K >= 2048 also splits its K loop
-                                         (fp32 partials + finalize: a different summation order) — only the fused-qkv remainder of
-                                         aether_dit_forward asks for it                                                           */
 /* Main loop (one; the lock-step, two-k-steps-per-slot, fragment-reads-in-the-compute-slot, four-wave and persistent-grid loops measured in
  * rounds 1-3 are recorded in profiles/r0*_gemm_*): "ping-pong" — the two waves that share a SIMD alternate "read fragments from LDS + issue
  * the next tile's LDS-DMA" and "issue MFMAs" slots, phase-locked by s_barrier. */
@@ -106,31 +103,11 @@ int aether_qk_norm_rope(const void* qkv, int B, int S, int H, int n_text, const 
                         const float* kn_w, const float* kn_b, float eps, const float* cos_t, const float* sin_t,
                         float q_scale, void* Qh, void* Kh, void* Vt, int Spad, void* stream);
 
-/* The same for the tokens s >= first_token (a multiple of 64) only — the tail rows of a forward whose leading rows were prepared in the
- * epilogue of aether_gemm_qkv_prep.  Covers the ragged last 64-token tile, i.e. also zeroes the pad columns of Vt. */
-int aether_qk_norm_rope_tail(const void* qkv, int B, int S, int H, int n_text, const float* qn_w, const float* qn_b, const float* kn_w,
-                             const float* kn_b, float eps, const float* cos_t, const float* sin_t, float q_scale, void* Qh, void* Kh,
-                             void* Vt, int Spad, int first_token, void* stream);
-
-/* Zero the pad columns [S, Spad) of Vt [rows = B*H*64, Spad] (attention multiplies them by p = 0: they must be finite). */
-int aether_vt_pad_zero(void* Vt, int rows, int S, int Spad, void* stream);
-
-/* Fused qkv projection + attention-operand preparation (north_star: "RMSNorm/RoPE as fused epilogues"): A [M,K] · Wqkv [3·heads·64, K]ᵀ + bias
- * with the work of aether_qk_norm_rope done on the accumulators in the GEMM epilogue — the projection is rounded to bf16 as the plain
- * epilogue would store it, then q / k: LayerNorm(64) per head + affine + 3-D RoPE on the video rows + q_scale on q -> Qh / Kh [B,H,S,64];
- * v: transposed store -> Vt [B,H,64,Spad] (pad columns NOT written: aether_vt_pad_zero / aether_qk_norm_rope_tail).  M = rows of whole
- * batch items, or the leading rows of one (the caller may keep a partly filled last round of tiles for the un-fused path).  Replaces
- * to_q / to_k / to_v + norm_q / norm_k + apply_rotary_emb of diffusers' CogVideoXAttnProcessor2_0 (reference call P:865-875).
- * flags: AETHER_GEMM_WIDE_STORE. */
-int aether_gemm_qkv_prep(const void* A, int lda, const void* W, int ldw, const float* bias, int M, int heads, int K, int S, int n_text,
-                         const float* qn_w, const float* qn_b, const float* kn_w, const float* kn_b, float eps, const float* cos_t,
-                         const float* sin_t, float q_scale, void* Qh, void* Kh, void* Vt, int Spad, int flags, void* stream);
-
-#define AETHER_DIT_FUSE_QKV_PREP 65536 /* flags bit 16 (aether_dit_forward): q/k norm + RoPE + V transpose in the qkv GEMM's epilogue
-                                          (aether_gemm_qkv_prep) instead of a pass of their own                                     */
-
 #define AETHER_ATTN_EXACT_MAX 32  /* flags bit 5: conservative path only: no shift-0 sweep — every row's shift is a true score maximum from
                                      its first tile on (generic tiles with the a-posteriori check); data-independent cost           */
+
+#define AETHER_ATTN_ROW_STORE 64  /* flags bit 6 (with AETHER_GEMM_WIDE_STORE): the 32 x 64 output block of a wave leaves through its LDS region as WHOLE
+                                     128-byte rows (eight rows per store instruction) instead of 16-byte pieces after a half-wave exchange          */
 
 /* Non-causal flash attention, head_dim 64: O[b,s,h*64+d] = softmax_2(Qh·Khᵀ)·V where softmax_2 uses base 2, i.e.
  * Qh must carry softmax_scale·log2(e) (see aether_qk_norm_rope).  Replaces F.scaled_dot_product_attention in
@@ -143,7 +120,7 @@ int aether_gemm_qkv_prep(const void* A, int lda, const void* W, int ldw, const f
  * the same with shift 0 for the whole sweep in a two-tile software pipeline; finished rows whose sum is not in [2^-100, inf) or
  * whose accumulators are not finite make the WORKGROUP redo its sweep on the conservative path.  Either way the results are those
  * of an exact fp32 soft-max; only speed depends on the data (|log2-domain score| > 100 is needed to leave the fast path).
- * flags: AETHER_GEMM_WIDE_STORE (16-byte epilogue stores), AETHER_ATTN_EXACT_MAX. */
+ * flags: AETHER_GEMM_WIDE_STORE (16-byte epilogue stores), AETHER_ATTN_EXACT_MAX, AETHER_ATTN_ROW_STORE. */
 int aether_flash_attn_fwd(const void* Qh, const void* Kh, const void* Vt, void* O, int B, int H, int S, int Spad, int flags, void* stream);
 
 /* Element-wise tail of one denoise step in ONE pass (aetherv1_pipeline_cogvideox.py:876-916): fp32 cast of the noise prediction (P:877),

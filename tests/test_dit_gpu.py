@@ -81,27 +81,6 @@ def test_dit_block_full_width(cuda, hip_lib):
     assert e_native < 1.5 * e_bf16 + 2e-3
 
 
-@pytest.mark.parametrize("case", ["small_b2", "full_width_tail_rows"])
-def test_dit_fused_qkv_epilogue_matches_the_two_pass_plan(cuda, hip_lib, case):
-    """AETHER_DIT_FUSE_QKV_PREP: q/k norm + RoPE + V^T in the qkv GEMM's epilogue.  Same oracle distance as the two-pass plan, and the two
-    plans agree far inside that distance.  "full_width_tail_rows": 226 + 14 x 60 x 90 / 4 ... = a B = 1 shape whose last round of tiles the
-    fused launch leaves to the un-fused GEMM + aether_qk_norm_rope_tail (rows_f < M)."""
-    from aether_amd import _lib
-    from oracle.dit import DitConfig
-    base = _lib.AETHER_GEMM_WIDE_STORE
-    if case == "small_b2":
-        cfg, shape = _small_cfg(), (2, 3, 8, 12)
-    else:
-        cfg, shape = DitConfig(num_layers=1, sample_frames=9), (1, 3, 60, 90)            # S = 226 + 4050 = 4276 rows: 17 row tiles x 36 = 612 tiles
-    a, ref, ref16 = _run_pair(cfg, *shape, cuda, flags=base)
-    b, _, _ = _run_pair(cfg, *shape, cuda, flags=base | _lib.AETHER_DIT_FUSE_QKV_PREP)
-    e_a, e_b, e_16, d_ab = _rel(a, ref), _rel(b, ref), _rel(ref16, ref), _rel(b, a)
-    print(f"{case}: two-pass {e_a:.3e}  fused epilogue {e_b:.3e}  bf16-oracle {e_16:.3e}  fused vs two-pass {d_ab:.3e}")
-    # two bf16 evaluations of the same arithmetic differ by bf16 rounding decisions (switching the attention loop moves this output by
-    # 3e-3, tools/r03/r03_diag_fuse_model.py): the plans must agree to within the bf16-oracle distance, and each must sit inside the usual bound
-    assert e_b < 1.5 * e_16 + 2e-3 and d_ab < e_16 + 1e-3
-
-
 def test_dit_rejects_bad_inputs(cuda, hip_lib):
     from aether_amd.transformer import AetherTransformer3D
     with pytest.raises(ValueError):

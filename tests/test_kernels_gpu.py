@@ -134,45 +134,6 @@ def test_gemm_tail_split_k(cuda, hip_lib, epi, gflags):
     assert diff_rows.numel() == 0 or diff_rows.min() >= 16 * 256 - 1024   # only tiles of the last row-tile group can differ
 
 
-@pytest.mark.parametrize("epi", ["bias", "gelu", "gate_res"])
-def test_gemm_lone_tail_split_k(cuda, hip_lib, epi):
-    """AETHER_GEMM_SPLIT_LONE_TAIL (flag 2, what aether_dit_forward passes for the un-fused remainder of the fused qkv projection): a launch of
-    64..128 tiles — less than ONE round — with K >= 2048 splits its K loop as well.  Without the flag the same call is a single launch."""
-    from aether_amd import ops
-    g = torch.Generator().manual_seed(23)
-    M, N, K = 5 * 256 - 30, 16 * 256, 2048                              # 80 tiles, 32 K tiles -> split over 3 workgroups each
-    A = torch.randn(M, K, generator=g).to(torch.bfloat16)
-    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
-    bias = torch.randn(N, generator=g)
-    y = A.float() @ W.float().t() + bias
-    kw = {}
-    if epi == "bias":
-        ref, code = y, ops.AETHER_EPI_BIAS
-    elif epi == "gelu":
-        ref, code = torch.nn.functional.gelu(y, approximate="tanh"), ops.AETHER_EPI_BIAS_GELU
-    else:
-        R = torch.randn(M, N, generator=g).to(torch.bfloat16)
-        gate = torch.randn(1, 2 * N, generator=g)
-        gsel = torch.where((torch.arange(M) < 100)[:, None], gate[0, N:], gate[0, :N])
-        ref, code = R.float() + gsel * y, ops.AETHER_EPI_BIAS_GATE_RES
-        gc = gate.to(cuda)
-        kw = dict(gate_vid=gc[:, :N], gate_txt=gc[:, N:], rows_per_batch=M, n_text=100)
-    ws = torch.empty(16 << 20, dtype=torch.float32, device=cuda)
-    outs = []
-    for flags in (1, 1 | 2, 1 | 2):
-        if epi == "gate_res":
-            x = R.to(cuda).clone()
-            ops.gemm_bf16(A.to(cuda), W.to(cuda), bias.to(cuda), code, R=x, out=x, flags=flags, splitk_ws=ws, **kw)
-            outs.append(x)
-        else:
-            outs.append(ops.gemm_bf16(A.to(cuda), W.to(cuda), bias.to(cuda), code, flags=flags, splitk_ws=ws))
-    torch.cuda.synchronize()
-    for o in outs:
-        _bf16_close(o, ref, f"gemm lone-tail split-K {epi}")
-    assert torch.equal(outs[1], outs[2])                               # deterministic
-    assert not torch.equal(outs[0], outs[1])                           # the flag did change the summation order (i.e. the split ran)
-
-
 def test_gemm_rejects_bad_shapes(cuda, hip_lib):
     from aether_amd import ops
     A = torch.zeros(64, 100, dtype=torch.bfloat16, device=cuda)
@@ -280,8 +241,8 @@ def test_qk_norm_rope(cuda, hip_lib, B, H, S, n_text):
     assert (Vt.cpu()[..., S:] == 0).all()
 
 
-# attention paths: the default (optimistic tile-pair sweep, conservative redo) with narrow / wide stores, and the conservative path alone (32)
-ATTN_FLAGS = [0, 1, 32, 32 | 1]
+# attention paths: the default (optimistic tile-pair sweep, conservative redo) with narrow / wide / whole-row stores, and the conservative path alone (32)
+ATTN_FLAGS = [0, 1, 32, 32 | 1, 64 | 1, 64 | 32 | 1]       # 64: whole 128-byte output rows through LDS
 
 
 def _attn_case(B, H, S, seed, q_gain=1.0):
@@ -465,37 +426,3 @@ def test_dpm_step_fused_is_bit_identical(cuda, hip_lib, nb, steps):
     for i, ((la, xa), (lb, xb)) in enumerate(zip(*outs)):
         assert torch.equal(la, lb), f"latents differ at step {i}: {(la.float() - lb.float()).abs().max().item()}"
         assert torch.equal(xa, xb), f"x0 differs at step {i}: {(xa - xb).abs().max().item()}"
-
-
-@pytest.mark.parametrize("B,H,S,n_text,K", [(1, 8, 700, 226, 512), (2, 4, 333, 20, 256), (1, 4, 1000, 0, 128)])
-@pytest.mark.parametrize("flags", [1, 0])
-def test_gemm_qkv_prep_matches_the_two_pass_path(cuda, hip_lib, B, H, S, n_text, K, flags):
-    """aether_gemm_qkv_prep = the qkv projection with q/k LayerNorm(64) + RoPE + scale and the V transpose in its epilogue, against
-    aether_gemm_bf16 followed by aether_qk_norm_rope.  V^T involves no arithmetic beyond the projection's rounding: bit-identical.  q / k
-    sum the 64 values of a head in a different order (32 + 32 across two lanes instead of 8 x 8), so the normalised values may differ in
-    the last bf16 bit of a few elements — and both must match the fp32 reference of the preparation like the stand-alone kernel does."""
-    from aether_amd import ops
-    from aether_amd._lib import ATTN_Q_SCALE
-    g = torch.Generator().manual_seed(S + K)
-    A = torch.randn(B * S, K, generator=g).to(torch.bfloat16)
-    W = (torch.randn(3 * H * 64, K, generator=g) * 1.5 / math.sqrt(K)).to(torch.bfloat16)
-    bias = 0.1 * torch.randn(3 * H * 64, generator=g)
-    _, qn_w, qn_b, kn_w, kn_b, cos, sin = _attn_inputs(B, H, S, n_text, 3)
-    c = lambda t: t.to(cuda)  # noqa: E731
-    qkv = ops.gemm_bf16(c(A), c(W), c(bias), ops.AETHER_EPI_BIAS, flags=flags).view(B, S, 3 * H * 64)
-    Q0, K0, V0 = ops.qk_norm_rope(qkv, H, n_text, c(qn_w), c(qn_b), c(kn_w), c(kn_b), 1e-6, c(cos), c(sin), ATTN_Q_SCALE)
-    Q1, K1, V1 = ops.gemm_qkv_prep(c(A), c(W), c(bias), H, S, n_text, c(qn_w), c(qn_b), c(kn_w), c(kn_b), 1e-6, c(cos), c(sin), ATTN_Q_SCALE, flags=flags)
-    torch.cuda.synchronize()
-    assert torch.equal(V0, V1)
-    for name, a, b in (("q", Q0, Q1), ("k", K0, K1)):
-        a, b = a.float(), b.float()
-        assert torch.isfinite(b).all()
-        differ = (a != b).float().mean().item()
-        worst = ((a - b).abs() / a.abs().clamp_min(1e-3)).max().item()
-        assert differ < 0.02 and worst <= 2.0 ** -6, (name, differ, worst)
-    if B == 1:          # leading rows only (what aether_dit_forward does when the last round of tiles would be mostly empty)
-        rows = 512
-        Q2, K2, V2 = ops.gemm_qkv_prep(c(A), c(W), c(bias), H, S, n_text, c(qn_w), c(qn_b), c(kn_w), c(kn_b), 1e-6, c(cos), c(sin), ATTN_Q_SCALE, flags=flags, rows=rows)
-        torch.cuda.synchronize()
-        assert torch.equal(Q2[:, :, :rows], Q1[:, :, :rows]) and torch.equal(K2[:, :, :rows], K1[:, :, :rows]) and torch.equal(V2[..., :rows], V1[..., :rows])
-        assert float(Q2[:, :, rows:].abs().max()) == 0 and torch.isnan(V2[..., rows:S].float()).all()      # rows beyond are untouched

@@ -443,13 +443,16 @@ def test_conv_tap_reuse_is_bit_identical(cuda, hip_lib, cin, cout, NB, T, H, W, 
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
-def test_decode_pair_is_bit_identical(cuda, hip_lib):
-    """AetherVAE.decode_pair: the two final decodes of a pipeline call (rgb and disparity latents, P:931,936) enqueued on two HIP streams over one set
-    of packed weights (second C handle + workspace).  Same kernels in the same order within each decode: bit-identical to the sequential calls —
-    eagerly, on the captured hipGraphs, and again after the roles of the inputs are swapped."""
+@pytest.mark.parametrize("lanes", [2, 1])
+def test_decode_pair_is_bit_identical(cuda, hip_lib, lanes):
+    """AetherVAE.decode_pair: the two final decodes of a pipeline call (rgb and disparity latents, P:931,936).  Two-lane launch plan (default): two
+    calls in a row, each with its tile batches on two streams.  One lane: the two decodes enqueued on two HIP streams over one set of packed weights
+    (second C handle + workspace).  Same kernels in the same order within each decode: bit-identical to the sequential calls — eagerly, on the
+    captured hipGraphs, and again after the roles of the inputs are swapped."""
+    from aether_amd import _lib
     from aether_amd.vae import AetherVAE
     kw = dict(block_out_channels=(64, 128, 128, 128), layers_per_block=1, sample_height=96, sample_width=240)
-    vae = AetherVAE(kw, device=cuda).init_random_weights(3)
+    vae = AetherVAE(kw, device=cuda, flags=_lib.AETHER_GEMM_WIDE_STORE | (_lib.AETHER_VAE_TWO_LANES if lanes == 2 else 0)).init_random_weights(3)
     vae.enable_tiling(); vae.enable_slicing()
     g = torch.Generator(device=cuda).manual_seed(0)
     za = torch.randn(1, 16, 5, 12, 30, generator=g, device=cuda).to(torch.bfloat16)

@@ -99,6 +99,24 @@ def cpu_baseline(cfg_overrides, S_video_shape, seconds_budget=30.0):
                       f"oracle, {dt:.1f} s), extrapolated x{cfg.num_layers}; host has {os.cpu_count()} logical cores"}
 
 
+def offline_cpu_figures():
+    """The UN-sampled CPU figures of the same oracle: what the full-size fixture runs took in the build container (8 vCPUs; recorded in the
+    fixtures' metadata by tools/make_fullsize_golden.py) — one whole 42-block forward, the whole 4-step reconstruction clip, the guided calls."""
+    import numpy as np
+    out = {"host": "build container, 8 vCPU (torch-CPU fp32 oracle)"}
+    gold = os.path.join(ROOT, "tests", "golden")
+    for key, fn, field in (("forward_42_blocks_s", "fullsize_dit.npz", "seconds_cpu"), ("reconstruction_clip_4_steps_s", "fullsize_clip.npz", "seconds_cpu_total"),
+                           ("prediction_2_guided_steps_s", "fullsize_prediction.npz", "seconds_cpu_total"),
+                           ("planning_2_guided_steps_s", "fullsize_planning.npz", "seconds_cpu_total")):
+        try:
+            out[key] = round(float(json.loads(str(np.load(os.path.join(gold, fn))["meta"]))[field]), 1)
+        except (OSError, KeyError, ValueError):
+            pass
+    if "forward_42_blocks_s" in out:
+        out["denoise_steps_per_s"] = round(1.0 / out["forward_42_blocks_s"], 5)
+    return out
+
+
 def cpu_baseline_vae():
     """fp32 oracle VAE (oracle/vae.py) on the host cores, bounded sample: ONE 240x360 tile x ONE 8-frame chunk of the encoder and
     ONE 30x45 latent tile x ONE 2-latent-frame chunk of the decoder, extrapolated by the tile x chunk count of the 41x480x720
@@ -591,6 +609,7 @@ def main():
             torch.cuda.empty_cache()
             line["cpu_baseline"] = cpu_baseline({"num_layers": args.layers}, (F_, H_, W_))
             line["cpu_baseline"]["covers"] = "the DiT steps only (>= 93 % of a 50-step clip); VAE: cpu_baseline_vae"
+            line["cpu_baseline"]["unsampled_offline"] = offline_cpu_figures()
             if not args.no_extra_legs:
                 line["cpu_baseline_vae"] = cpu_baseline_vae()
         print(json.dumps(line), flush=True)

@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU oracle of the parity tests is mostly small fp32 operators: on the GPU box's 256 logical cores torch's default (one thread per
+    # physical core) spends its time in thread hand-offs — the toy-geometry fixture run took 124 s there against 0.2 s on 8 cores.
+    import torch
+    if (os.cpu_count() or 1) > 32 and "OMP_NUM_THREADS" not in os.environ:
+        torch.set_num_threads(32)
 
 
 @pytest.fixture(scope="session")

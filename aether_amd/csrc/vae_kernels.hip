@@ -113,6 +113,21 @@ __global__ __launch_bounds__(256) void resample_pad_kernel(ResampleArgs p) {
         }
         *(uint4*)(p.y + ((((size_t)nb * p.oT + t + p.pt) * p.oH + h + p.ph) * p.oW + w + p.pw) * p.C + oct * 8) = out;
     }
+    // everything of the padded volume outside the interior box is zero (round 4: the volume is arena memory of the launch plan, rewritten
+    // by every producer, not a persistent zero-bordered pool entry)
+    const long vol = (long)p.oT * p.oH * p.oW * oct_per_vox;
+    if (vol != total) {
+        const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+        for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < vol; idx += (long)gridDim.x * blockDim.x) {
+            const int oct = idx % oct_per_vox;
+            long v = idx / oct_per_vox;
+            const int w = v % p.oW; long r = v / p.oW;
+            const int h = r % p.oH;
+            const int t = r / p.oH;
+            const bool inside = t >= p.pt && t < p.pt + p.nT && h >= p.ph && h < p.ph + p.nH && w >= p.pw && w < p.pw + p.nW;
+            if (!inside) *(uint4*)(p.y + ((((size_t)nb * p.oT + t) * p.oH + h) * p.oW + w) * p.C + oct * 8) = zero;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

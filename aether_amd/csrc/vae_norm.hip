@@ -220,6 +220,28 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(GnApplyArgs p) {
             }
         }
     }
+    // ---- zero border of the padded volume (round 4: the volumes are arena memory of the launch plan, not persistent zero-bordered pool
+    // entries): this workgroup owns padded row h + ph of frame t + pt — and of the two causal front frames when t == 0 — i.e. that row's
+    // left / right border voxels, plus the rows above (h == 0) and below (h == H - 1) the interior
+    {
+        const int vec_per_vox = opv;                                  // 16-byte pieces per voxel
+        const size_t prow = (size_t)p.oW * p.C;                       // elements of one padded row
+        const int right = p.oW - p.pw - p.W, below = p.oH - p.ph - p.H;
+        const int nfr = (p.causal && t == 0) ? 3 : 1;                 // frame t (+ the two front frames)
+        const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+        for (int fi = 0; fi < nfr; ++fi) {
+            unsigned short* row0 = yrow - (size_t)p.pw * p.C - (size_t)fi * plane;      // start of this padded row in frame t + pt - fi
+            for (int u = threadIdx.x; u < (p.pw + right) * vec_per_vox; u += 256) {
+                const int vx = u >> p.log2_opv, o8 = (u & (opv - 1)) << 3;
+                const int col = vx < p.pw ? vx : p.pw + p.W + (vx - p.pw);
+                *(uint4*)(row0 + (size_t)col * p.C + o8) = zero;
+            }
+            if (h == 0)
+                for (int u = threadIdx.x; u < p.ph * p.oW * vec_per_vox; u += 256) *(uint4*)(row0 - (size_t)p.ph * prow + (size_t)u * 8) = zero;
+            if (h == p.H - 1)
+                for (int u = threadIdx.x; u < below * p.oW * vec_per_vox; u += 256) *(uint4*)(row0 + prow + (size_t)u * 8) = zero;
+        }
+    }
     if (p.causal && t == 0 && p.front_prev != nullptr) {             // later chunks: front frames = the saved pair, row by row
         const unsigned short* prow = p.front_prev + (size_t)nb * 2 * plane + row_in_plane;
         const int vecs = p.W << p.log2_opv;

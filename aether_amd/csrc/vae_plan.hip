@@ -203,24 +203,10 @@ struct Plan {
         return &it->second;
     }
 
-    // pool: zero-bordered volume of this shape (persistent across calls in one workspace)
-    char* padded(int NB, int T, int H, int W, int C) {
-        const Shape5 key(lane, NB, T, H, W, C);
-        const size_t bytes = align_up((size_t)NB * T * H * W * C * 2, 256);
-        if (dry) {
-            if (h->pool.count(key) || dry_pool.count(key)) return reinterpret_cast<char*>((uintptr_t)256);
-            dry_pool[key] = pool_need; pool_need += bytes;
-            return reinterpret_cast<char*>((uintptr_t)256);
-        }
-        auto it = h->pool.find(key);
-        if (it == h->pool.end()) {
-            if (h->pool_bytes + bytes > h->pool_cap) { fail(AETHER_ERR_ARG, "vae: workspace pool region too small (query aether_vae_workspace_bytes for this call)"); return nullptr; }
-            it = h->pool.emplace(key, h->pool_bytes).first;
-            h->pool_bytes += bytes;
-            if (hipMemsetAsync(h->ws + it->second, 0, bytes, stream) != hipSuccess) { fail(AETHER_ERR_LAUNCH, "vae: memset failed"); return nullptr; }
-        }
-        return h->ws + it->second;
-    }
+    // zero-bordered convolution input volume: arena memory with the lifetime of the convolution that reads it.  Its producers write EVERY
+    // voxel — interior, causal front frames and the zero border (aether_groupnorm_apply*, aether_resample_pad) — so nothing persists from call
+    // to call (rounds 1-3 kept one volume per distinct shape in a pool whose borders were zeroed once: 15.7 GB of the decoder's workspace).
+    char* padded(int NB, int T, int H, int W, int C) { return alloc((size_t)NB * T * H * W * C * 2); }
     const int* tap_table(int kt, int kh, int kw, int iH, int iW, int iC, int* n_taps) {
         const auto key = std::make_tuple(lane, kt, kh, kw, iH, iW, iC);
         const int n = kt * kh * kw * (iC / 64);
@@ -341,8 +327,12 @@ struct Plan {
         char* next = nullptr;
         if (reserve_mode) reserve_list.emplace_back(key, (size_t)x.NB * 2 * (x.H + 2) * (x.W + 2) * x.C * 2);
         else causal_buffers(key, &prev, &next);
+        if (dst == nullptr) dst = alloc((size_t)x.NB * x.T * x.H * x.W * cw.cout_pad * 2);    // the output first: volume + norm scratch sit above it ...
+        const size_t mark = top;
         char* vol = norm_to_padded(x, nw, 2, 1, zq, eps, prev, next);
-        return conv_gemm(vol, x.NB, x.T + 2, x.H + 2, x.W + 2, x.C, cw, x.T, x.H, x.W, 1, residual, dst);
+        Act y = conv_gemm(vol, x.NB, x.T + 2, x.H + 2, x.W + 2, x.C, cw, x.T, x.H, x.W, 1, residual, dst);
+        top = mark;                                                                          // ... and are released once the convolution is enqueued
+        return y;
     }
     Act resnet(const Act& x, const std::string& prefix, const Act* zq) {
         const NormW *n1 = norm(prefix + "norm1"), *n2 = norm(prefix + "norm2");
@@ -395,8 +385,11 @@ struct Plan {
                 if (rc) break;
                 const bool ct = i < tlevel;
                 const int Tn = ct ? ((x.T & 1) ? x.T / 2 + 1 : x.T / 2) : x.T;
+                char* out = alloc((size_t)x.NB * Tn * (x.H / 2) * (x.W / 2) * ds->cout_pad * 2);
+                const size_t mark = top;
                 char* vol = resample(x, ct ? 1 : 0, Tn, x.H + 1, x.W + 1, 0, 0, 0);
-                x = conv_gemm(vol, x.NB, Tn, x.H + 1, x.W + 1, x.C, *ds, Tn, x.H / 2, x.W / 2, 2, nullptr);
+                x = conv_gemm(vol, x.NB, Tn, x.H + 1, x.W + 1, x.C, *ds, Tn, x.H / 2, x.W / 2, 2, nullptr, out);
+                top = mark;
             }
         }
         for (int j = 0; j < 2 && !rc; ++j) x = resnet(x, "encoder.mid_block.resnets." + std::to_string(j) + ".", nullptr);
@@ -431,8 +424,11 @@ struct Plan {
                 if (rc) break;
                 int Tn = x.T, mode = 2;
                 if (i < tlevel) { Tn = x.T > 1 ? ((x.T & 1) ? 2 * x.T - 1 : 2 * x.T) : 1; mode = 3; }
+                char* out = alloc((size_t)x.NB * Tn * (2 * x.H) * (2 * x.W) * us->cout_pad * 2);
+                const size_t mark = top;
                 char* vol = resample(x, mode, Tn, 2 * x.H + 2, 2 * x.W + 2, 0, 1, 1);
-                x = conv_gemm(vol, x.NB, Tn, 2 * x.H + 2, 2 * x.W + 2, x.C, *us, Tn, 2 * x.H, 2 * x.W, 1, nullptr);
+                x = conv_gemm(vol, x.NB, Tn, 2 * x.H + 2, 2 * x.W + 2, x.C, *us, Tn, 2 * x.H, 2 * x.W, 1, nullptr, out);
+                top = mark;
             }
         }
         if (rc) return x;

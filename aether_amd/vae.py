@@ -301,12 +301,12 @@ class AetherVAE:
         if need == 0:
             raise RuntimeError("aether_vae_workspace_bytes: " + self._lib.aether_last_error().decode())
         if self._workspace is None or self._workspace.numel() < need:
-            # a fresh workspace resets the library's pool of zero-bordered volumes: leave head-room for the other direction's shapes
+            # one workspace for both directions, grown to the larger need (nothing in it persists from call to call except the tiny
+            # tap-offset tables, which the library regenerates when the pointer changes)
             self._workspace = None
             self._graphs.clear()
             torch.cuda.empty_cache()
-            old = 0 if self._ws_bytes is None else self._ws_bytes
-            self._ws_bytes = max(int(need * 1.5), old + need) + (1 << 20)      # monotone: the pool of BOTH directions ends up fitting
+            self._ws_bytes = max(int(need), 0 if self._ws_bytes is None else self._ws_bytes) + (1 << 20)
             self._workspace = torch.empty(self._ws_bytes, dtype=torch.uint8, device=self.device)
         fn = self._lib.aether_vae_decode if decode else self._lib.aether_vae_encode
         what = "aether_vae_decode" if decode else "aether_vae_encode"

@@ -155,16 +155,30 @@ def test_reconstruction_trajectory_ten_steps(cuda, modules):
     dit, vae = modules
     z, meta = _load("fullsize_traj.npz")
     pipe = _pipeline(dit, vae)
-    pipe.decode_concurrently = False
-    per_step = []
     ref_steps = z["step_latents_s6"]
 
+    _, rec = _trajectory(pipe, fc.TRAJ_STEPS)
+    per_step = [rec[i] for i in range(fc.TRAJ_STEPS)]
+    assert len(per_step) == fc.TRAJ_STEPS == ref_steps.shape[0]
+    errs = [fc.metrics(per_step[i].to(torch.bfloat16).float(), fc.from_bf16_bits(ref_steps[i]).float())["rel_l2"] for i in range(fc.TRAJ_STEPS)]
+    fin = fc.metrics(pipe._final_latents.cpu().float()[..., ::2, ::2], fc.from_bf16_bits(z["final_latents_s2_bits"]).float())
+    print("\n[fullsize] 10-step reconstruction trajectory, latents rel-L2 vs fp32 oracle after each step: " + " ".join(f"{e:.2e}" for e in errs)
+          + f"; final (every 2nd pixel): rel-L2 {fin['rel_l2']:.3e}  L-inf {100 * fin['linf_rel']:.2f} % of max")
+    assert max(errs) <= 3.0e-2 and fin["rel_l2"] <= 3.0e-2 and fin["linf_rel"] <= 0.06, (errs, fin)
+
+
+def _trajectory(pipe, steps, keep=None):
+    """Run the reconstruction call with a scheduler that records the latents every step hands back (every 6th row / column)."""
     from aether_amd.scheduler import CogVideoXDPMScheduler
+    rec = {}
 
     class Spy(CogVideoXDPMScheduler):
-        """records the latents each step hands back (the pipeline keeps no per-step callback)"""
+        n = 0
+
         def _rec(self, res):
-            per_step.append(res[0][:, :, :, ::6, ::6].float().cpu())
+            if keep is None or Spy.n in keep:
+                rec[Spy.n] = res[0][:, :, :, ::6, ::6].float().cpu()
+            Spy.n += 1
             return res
 
         def step(self, *a, **kw):
@@ -174,11 +188,28 @@ def test_reconstruction_trajectory_ten_steps(cuda, modules):
             return self._rec(super().step_fused(*a, **kw))
 
     pipe.scheduler = Spy()
-    pipe(task="reconstruction", video=fc.clip_video(), height=fc.HEIGHT, width=fc.WIDTH, num_frames=fc.FRAMES, fps=12,
-         num_inference_steps=fc.TRAJ_STEPS, generator=torch.Generator().manual_seed(fc.CLIP_SEED))
-    assert len(per_step) == fc.TRAJ_STEPS == ref_steps.shape[0]
-    errs = [fc.metrics(per_step[i].to(torch.bfloat16).float(), fc.from_bf16_bits(ref_steps[i]).float())["rel_l2"] for i in range(fc.TRAJ_STEPS)]
+    out = pipe(task="reconstruction", video=fc.clip_video(), height=fc.HEIGHT, width=fc.WIDTH, num_frames=fc.FRAMES, fps=12,
+               num_inference_steps=steps, generator=torch.Generator().manual_seed(fc.CLIP_SEED))
+    return out, rec
+
+
+def test_headline_reconstruction_fifty_steps(cuda, modules):
+    """BASELINE configs[1] ITSELF — "4D reconstruction, 41x480x720, 50 steps" — against the fp32 oracle's whole 50-step call (5.6 h of CPU
+    offline, tools/make_fullsize_golden.py traj50): latents along the trajectory, final latents (L-inf / rel-L2), decoded rgb PSNR and disparity."""
+    path = os.path.join(fc.GOLDEN_DIR, "fullsize_traj50.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/fullsize_traj50.npz not generated yet (tools/make_fullsize_golden.py traj50: ~6 h of CPU)")
+    dit, vae = modules
+    z, meta = _load("fullsize_traj50.npz")
+    pipe = _pipeline(dit, vae)
+    kept = list(meta["kept_steps"])
+    out, rec = _trajectory(pipe, fc.HEADLINE_STEPS, set(kept))
+    errs = [fc.metrics(rec[i].to(torch.bfloat16).float(), fc.from_bf16_bits(z["step_latents_s6"][k]).float())["rel_l2"] for k, i in enumerate(kept)]
     fin = fc.metrics(pipe._final_latents.cpu().float()[..., ::2, ::2], fc.from_bf16_bits(z["final_latents_s2_bits"]).float())
-    print("\n[fullsize] 10-step reconstruction trajectory, latents rel-L2 vs fp32 oracle after each step: " + " ".join(f"{e:.2e}" for e in errs)
-          + f"; final (every 2nd pixel): rel-L2 {fin['rel_l2']:.3e}  L-inf {100 * fin['linf_rel']:.2f} % of max")
-    assert max(errs) <= 3.0e-2 and fin["rel_l2"] <= 3.0e-2 and fin["linf_rel"] <= 0.06, (errs, fin)
+    s = fc.DEC_STRIDE
+    p_rgb = fc.psnr(torch.from_numpy(out.rgb)[:, ::s, ::s], torch.from_numpy(z["rgb_s8"].astype(np.float32)))
+    m_disp = fc.metrics(torch.from_numpy(out.disparity)[:, ::s, ::s], torch.from_numpy(z["disparity_s8"].astype(np.float32)))
+    print("\n[fullsize] HEADLINE config, 50-step reconstruction: latents rel-L2 vs fp32 oracle after steps " + ", ".join(f"{i}: {e:.2e}" for i, e in zip(kept, errs))
+          + f"; final (every 2nd pixel): rel-L2 {fin['rel_l2']:.3e}  L-inf {100 * fin['linf_rel']:.2f} % of max; rgb PSNR {p_rgb:.1f} dB; disparity rel-L2 {m_disp['rel_l2']:.3e}"
+          + f" ({meta['seconds_cpu_total']:.0f} s of CPU offline)")
+    assert np.isfinite(out.rgb).all() and fin["rel_l2"] <= 0.12 and p_rgb >= 25.0, (errs, fin, p_rgb)      # loose until measured; tightened in DESIGN §2 / here

@@ -41,6 +41,8 @@ CLIP_STEPS = 4                               # the reference's default for recon
 GUIDED_STEPS = 2                             # guided steps of the prediction / planning fixtures (2 x B = 2 = four 42-block forwards)
 GUIDED_SEED = 42
 TRAJ_STEPS = 10                              # the longer reconstruction trajectory (drift against the step count: 4 -> 10)
+HEADLINE_STEPS = 50                          # BASELINE configs[1] itself: reconstruction, 50 steps
+HEADLINE_KEEP = (0, 1, 2, 3, 4, 6, 9, 14, 19, 24, 29, 34, 39, 44, 49)   # steps whose latents the 50-step fixture keeps
 DEC_STRIDE = 8                               # decoded pixels kept in the fixture: every 8th row / column, all frames
 
 

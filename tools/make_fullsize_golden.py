@@ -151,12 +151,14 @@ def stage_guided(dit, task):
     log(f"{task}: wrote tests/golden/fullsize_{task}.npz")
 
 
-def stage_traj(dit):
-    """The reconstruction call of `stage_clip` (same clip, same seed -> same posterior sample and initial latents) with TRAJ_STEPS steps
-    and no decodes: per-step latents (every 6th row / column) and the final latents (every 2nd) — how the drift against the fp32
-    oracle grows with the number of steps."""
+def stage_traj(dit, steps=None, name="fullsize_traj.npz", with_decodes=False, keep_steps=None):
+    """The reconstruction call of `stage_clip` (same clip, same seed -> same posterior sample and initial latents) with `steps` steps: per-step
+    latents (every 6th row / column; all steps, or `keep_steps`) and the final latents (every 2nd) — how the drift against the fp32 oracle
+    grows with the number of steps.  `steps` = TRAJ_STEPS (10, no decodes) for the growth law; `steps` = 50 with decodes = BASELINE configs[1]
+    itself ("4D reconstruction, 41x480x720, 50 steps"): final latents and the decoded rgb / disparity of the headline configuration."""
     from aether_amd.scheduler import CogVideoXDPMScheduler
     from oracle.pipeline import sample
+    steps = steps or fc.TRAJ_STEPS
 
     class NoDecode:
         """The decodes of P:931,936 are irrelevant to the latent trajectory: replace them by zeros of the right shape."""
@@ -170,30 +172,38 @@ def stage_traj(dit):
             import types
             return types.SimpleNamespace(sample=torch.zeros(z.shape[0], 3, (z.shape[2] - 1) * 4 + 1, z.shape[3] * 8, z.shape[4] * 8, dtype=z.dtype))
 
-    vae = NoDecode(fc.build_oracle_vae())
+    vae = fc.build_oracle_vae()
+    if not with_decodes:
+        vae = NoDecode(vae)
     v = fc.video_as_model_input(fc.clip_video())
-    step_lat, times, mark = [], {}, [time.perf_counter()]
+    step_lat, times, mark = {}, {}, [time.perf_counter()]
 
     def on_step(i, latents):
         now = time.perf_counter()
         times[f"step{i}"] = now - mark[0]
         mark[0] = now
-        step_lat.append(latents[:, :, :, ::6, ::6].clone())
-        log(f"traj: step {i} done ({times[f'step{i}']:.1f} s)")
+        if keep_steps is None or i in keep_steps:
+            step_lat[i] = latents[:, :, :, ::6, ::6].clone()
+        log(f"traj{steps}: step {i} done ({times[f'step{i}']:.1f} s)")
 
     trace = {"on_step": on_step}
     t0 = time.perf_counter()
-    sample("reconstruction", dit, vae, CogVideoXDPMScheduler(), fc.prompt_embeds(), video=v, height=fc.HEIGHT, width=fc.WIDTH,
-           num_frames=fc.FRAMES, num_inference_steps=fc.TRAJ_STEPS, generator=torch.Generator().manual_seed(fc.CLIP_SEED),
-           rope=fc.rope_tables(), compute_dtype=torch.float32, trace=trace)
+    rgb, disp, rm = sample("reconstruction", dit, vae, CogVideoXDPMScheduler(), fc.prompt_embeds(), video=v, height=fc.HEIGHT, width=fc.WIDTH,
+                           num_frames=fc.FRAMES, num_inference_steps=steps, generator=torch.Generator().manual_seed(fc.CLIP_SEED),
+                           rope=fc.rope_tables(), compute_dtype=torch.float32, trace=trace)
     total = time.perf_counter() - t0
-    meta = dict(seconds_cpu_total=total, step_seconds=times, threads=torch.get_num_threads(), torch=torch.__version__, steps=fc.TRAJ_STEPS,
-                dit_seed=fc.DIT_SEED, vae_seed=fc.VAE_SEED, clip_seed=fc.CLIP_SEED,
+    kept = sorted(step_lat)
+    meta = dict(seconds_cpu_total=total, step_seconds=times, threads=torch.get_num_threads(), torch=torch.__version__, steps=steps,
+                dit_seed=fc.DIT_SEED, vae_seed=fc.VAE_SEED, clip_seed=fc.CLIP_SEED, kept_steps=kept, with_decodes=with_decodes,
                 noise_pred_rms=[float(p.pow(2).mean().sqrt()) for p in trace["noise_pred"]])
-    np.savez_compressed(os.path.join(fc.GOLDEN_DIR, "fullsize_traj.npz"),
-                        step_latents_s6=np.stack([fc.bf16_bits(x) for x in step_lat]),
-                        final_latents_s2_bits=fc.bf16_bits(trace["final_latents"][..., ::2, ::2]), meta=json.dumps(meta))
-    log(f"traj: {fc.TRAJ_STEPS}-step reconstruction trajectory took {total:.1f} s; wrote tests/golden/fullsize_traj.npz")
+    arrays = dict(step_latents_s6=np.stack([fc.bf16_bits(step_lat[i]) for i in kept]),
+                  final_latents_s2_bits=fc.bf16_bits(trace["final_latents"][..., ::2, ::2]), meta=json.dumps(meta))
+    if with_decodes:
+        s = fc.DEC_STRIDE
+        arrays["rgb_s8"] = rgb[:, ::s, ::s].numpy().astype(np.float16)
+        arrays["disparity_s8"] = disp[:, ::s, ::s].numpy().astype(np.float16)
+    np.savez_compressed(os.path.join(fc.GOLDEN_DIR, name), **arrays)
+    log(f"traj: {steps}-step reconstruction trajectory took {total:.1f} s; wrote tests/golden/{name}")
 
 
 def main():
@@ -212,6 +222,8 @@ def main():
             stage_guided(dit, task)
     if "traj" in stages:
         stage_traj(dit)
+    if "traj50" in stages:
+        stage_traj(dit, steps=fc.HEADLINE_STEPS, name="fullsize_traj50.npz", with_decodes=True, keep_steps=fc.HEADLINE_KEEP)
 
 
 if __name__ == "__main__":

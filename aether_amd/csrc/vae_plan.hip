@@ -50,8 +50,8 @@ struct AetherVae {
     size_t pool_cap = 0;                  // pool region size of the current workspace
     // ---- second lane (AETHER_VAE_TWO_LANES): the tile groups of one call are independent; half of them are enqueued on a stream of the
     // handle's own, forked from / joined to the caller's stream with events (capturable: the side stream joins the caller's capture)
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
 };
 
 namespace {
@@ -177,8 +177,9 @@ struct Plan {
     std::map<std::tuple<int, int, int, int, int, int, int>, size_t> dry_taps;
     float* splitk = nullptr; size_t splitk_bytes = 0;
     int lane = 0;                     // lane whose groups are being enqueued: selects `stream`, `splitk` and the pool entries
-    hipStream_t lane_stream[2] = {nullptr, nullptr};
-    float* lane_splitk[2] = {nullptr, nullptr};
+    int n_lanes = 1;
+    hipStream_t lane_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* lane_splitk[4] = {nullptr, nullptr, nullptr, nullptr};
     void set_lane(int l) { lane = l; stream = lane_stream[l]; splitk = lane_splitk[l]; }
     int rc = 0;
     std::string err;
@@ -473,10 +474,11 @@ struct Plan {
         const auto ch = chunks(T, bs);
         const int To = total_out_frames(c, decode, T);
         const int oC = decode ? c.out_channels : 2 * c.latent_channels;
-        // groups of equally shaped tiles: up to 4 per launch batch on one lane, up to 2 with two lanes (every tile's arithmetic is
-        // independent of its batch: GroupNorm statistics are per batch item, a convolution row depends on its own voxels only)
-        const bool two_lanes = (c.flags & AETHER_VAE_TWO_LANES) != 0 && nrow * ncol > 1;
-        const size_t gmax = two_lanes ? 2 : 4;
+        // groups of equally shaped tiles, up to 4 per launch batch (every tile's arithmetic is independent of its batch: GroupNorm statistics
+        // are per batch item, a convolution row depends on its own voxels only)
+        const int NL = (nrow * ncol > 1) ? n_lanes : 1;
+        const bool two_lanes = NL > 1;
+        const size_t gmax = 4;
         struct Group { int th, tw; std::vector<int> idx; int lane = 0; };
         std::vector<Group> groups;
         for (int i = 0; i < nrow; ++i)
@@ -500,23 +502,31 @@ struct Plan {
             oth[k] = decode ? th * down : th / down; otw[k] = decode ? tw * down : tw / down;
             full[k] = alloc((size_t)To * oth[k] * otw[k] * ldc * 2);
         }
-        // lanes: groups in order of decreasing area, each to the lane with less work so far (480x720: two groups of two full tiles,
-        // then 2 x (240x144) | 2 x (80x360) + (80x144): 241.9k pixels of tiles per lane); lane 0 is enqueued on the caller's stream
+        // lanes: groups in order of decreasing area, each to the lane with less work so far.  480x720: lane 0 (the caller's stream) takes the
+        // batch of the four full tiles (71 % of the pixels), lane 1 the three batches of edge tiles (2 x 240x144, 2 x 80x360, 80x144).  Measured
+        // (profiles/r04_vae_lanes_sweep.txt): batches of four on two lanes beat balanced batches of two (encode 0.188 vs 0.197 s, decode 0.377
+        // vs 0.387 s: the big batches keep the deep, low-resolution layers out of split-K and halve the launches), and a third or fourth lane
+        // loses again (0.203 / 0.398, 0.193 / 0.385)
         if (two_lanes) {
             std::vector<int> order(groups.size());
             for (size_t i = 0; i < groups.size(); ++i) order[i] = (int)i;
             auto area = [&](int i) { return (long)groups[i].th * groups[i].tw * (long)groups[i].idx.size(); };
             std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return area(a) > area(b); });
-            long load[2] = {0, 0};
-            for (int i : order) { const int l = load[1] < load[0] ? 1 : 0; groups[i].lane = l; load[l] += area(i); }
+            long load[4] = {0, 0, 0, 0};
+            for (int i : order) {
+                int l = 0;
+                for (int k = 1; k < NL; ++k) if (load[k] < load[l]) l = k;
+                groups[i].lane = l; load[l] += area(i);
+            }
             if (!dry) {
-                if (hipEventRecord(h->ev_fork, lane_stream[0]) != hipSuccess || hipStreamWaitEvent(lane_stream[1], h->ev_fork, 0) != hipSuccess)
-                    return fail(AETHER_ERR_LAUNCH, "vae: fork of the second lane failed");
+                if (hipEventRecord(h->ev_fork, lane_stream[0]) != hipSuccess) return fail(AETHER_ERR_LAUNCH, "vae: fork of the lanes failed");
+                for (int k = 1; k < NL; ++k)
+                    if (hipStreamWaitEvent(lane_stream[k], h->ev_fork, 0) != hipSuccess) return fail(AETHER_ERR_LAUNCH, "vae: fork of the lanes failed");
             }
         }
         size_t lane_base = top;
-        for (int pass = 0; pass < (two_lanes ? 2 : 1); ++pass) {
-          if (pass == 1) lane_base = align_up(peak, 256);            // lane 1's arena starts where lane 0's ends
+        for (int pass = 0; pass < NL; ++pass) {
+          if (pass >= 1) lane_base = align_up(peak, 256);            // lane k's arena starts where lane k-1's ends
           set_lane(pass);
           const size_t mark_call = lane_base;
           for (auto& g : groups) {
@@ -566,8 +576,9 @@ struct Plan {
         }
         set_lane(0);
         if (two_lanes && !dry) {
-            if (hipEventRecord(h->ev_join, lane_stream[1]) != hipSuccess || hipStreamWaitEvent(lane_stream[0], h->ev_join, 0) != hipSuccess)
-                return fail(AETHER_ERR_LAUNCH, "vae: join of the second lane failed");
+            for (int k = 1; k < NL; ++k)
+                if (hipEventRecord(h->ev_join[k - 1], lane_stream[k]) != hipSuccess || hipStreamWaitEvent(lane_stream[0], h->ev_join[k - 1], 0) != hipSuccess)
+                    return fail(AETHER_ERR_LAUNCH, "vae: join of the lanes failed");
         }
         caches = nullptr;
         // assemble
@@ -588,40 +599,47 @@ struct Plan {
 
 constexpr size_t kVaeSplitKBytes = (size_t)96 << 20;
 
+int vae_lanes(const AetherVae* h) { return (h->cfg.flags & AETHER_VAE_TWO_LANES) ? 2 : 1; }
+
 int vae_run(AetherVae* h, bool decode, const void* src, int T, int H, int W, int tiling, void* out, void* workspace, size_t workspace_bytes,
             void* stream, size_t* need_out) {
-    Plan dry; dry.h = h; dry.stream = nullptr; dry.dry = true;
+    const int NL = vae_lanes(h);
+    Plan dry; dry.h = h; dry.stream = nullptr; dry.dry = true; dry.n_lanes = NL;
     int oT, oH, oW;
-    dry.alloc(2 * kVaeSplitKBytes);
+    dry.alloc(NL * kVaeSplitKBytes);
     if (!dry.run(decode, src, T, H, W, tiling, nullptr, &oT, &oH, &oW)) return aether_set_error(dry.rc, dry.err.c_str());
     const size_t pool_total = h->pool_bytes + dry.pool_need;
     const size_t need = align_up(pool_total, 256) + dry.peak;
     if (need_out) { *need_out = need; return AETHER_OK; }
     if (!workspace || ((uintptr_t)workspace & 255)) return aether_set_error(AETHER_ERR_ALIGN, "vae: workspace must be non-null and 256-byte aligned");
     if (workspace_bytes < need) return aether_set_error(AETHER_ERR_ARG, "vae: workspace too small (aether_vae_workspace_bytes)");
-    if (h->ws != (char*)workspace || h->ws_bytes != workspace_bytes) {        // a new workspace: nothing in it is zeroed yet
+    if (h->ws != (char*)workspace || h->ws_bytes != workspace_bytes) {        // a new workspace: the tap tables have to be generated in it again
         h->ws = (char*)workspace; h->ws_bytes = workspace_bytes;
         h->pool.clear(); h->taps.clear(); h->pool_bytes = 0;
-        // after a reset the pool must hold every shape of this call again
-        Plan d2; d2.h = h; d2.dry = true; d2.alloc(2 * kVaeSplitKBytes);
+        Plan d2; d2.h = h; d2.dry = true; d2.n_lanes = NL; d2.alloc(NL * kVaeSplitKBytes);
         if (!d2.run(decode, src, T, H, W, tiling, nullptr, &oT, &oH, &oW)) return aether_set_error(d2.rc, d2.err.c_str());
         if (align_up(d2.pool_need, 256) + d2.peak > workspace_bytes) return aether_set_error(AETHER_ERR_ARG, "vae: workspace too small");
     }
-    // the pool region may grow up to where this call's arena begins; the arena sits at the END of the workspace
-    Plan p; p.h = h; p.stream = (hipStream_t)stream; p.dry = false;
+    // the table region may grow up to where this call's arena begins; the arena sits at the END of the workspace
+    Plan p; p.h = h; p.stream = (hipStream_t)stream; p.dry = false; p.n_lanes = NL;
     p.arena = (char*)workspace + (workspace_bytes - align_up(dry.peak, 256)) / 256 * 256;
     h->pool_cap = (size_t)(p.arena - (char*)workspace);
-    if ((h->cfg.flags & AETHER_VAE_TWO_LANES) && h->side == nullptr) {
-        // a HIGH-PRIORITY stream: priority streams get hardware queues of their own, a normal stream may share the caller's queue (4 queues,
-        // round robin) and then nothing overlaps (profiles/r03_decode_pair.json)
-        int lo = 0, hi = 0;
-        hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, hi) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)
-            return aether_set_error(AETHER_ERR_LAUNCH, "vae: could not create the second lane's stream / events");
+    p.lane_stream[0] = (hipStream_t)stream;
+    for (int k = 1; k < NL; ++k) {
+        if (h->side[k - 1] == nullptr) {
+            // HIGH-PRIORITY streams: priority streams get hardware queues of their own, a normal stream may share the caller's queue (4 queues,
+            // round robin) and then nothing overlaps (profiles/r03_decode_pair.json)
+            int lo = 0, hi = 0;
+            hipDeviceGetStreamPriorityRange(&lo, &hi);
+            if (hipStreamCreateWithPriority(&h->side[k - 1], hipStreamNonBlocking, hi) != hipSuccess ||
+                hipEventCreateWithFlags(&h->ev_join[k - 1], hipEventDisableTiming) != hipSuccess ||
+                (h->ev_fork == nullptr && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess))
+                return aether_set_error(AETHER_ERR_LAUNCH, "vae: could not create a lane's stream / events");
+        }
+        p.lane_stream[k] = h->side[k - 1];
     }
-    p.lane_stream[0] = (hipStream_t)stream; p.lane_stream[1] = h->side ? h->side : (hipStream_t)stream;
-    p.lane_splitk[0] = (float*)p.alloc(kVaeSplitKBytes); p.lane_splitk[1] = (float*)p.alloc(kVaeSplitKBytes); p.splitk_bytes = kVaeSplitKBytes;
+    for (int k = 0; k < NL; ++k) p.lane_splitk[k] = (float*)p.alloc(kVaeSplitKBytes);
+    p.splitk_bytes = kVaeSplitKBytes;
     p.set_lane(0);
     if (!p.run(decode, src, T, H, W, tiling, out, &oT, &oH, &oW)) return aether_set_error(p.rc, p.err.c_str());
     return AETHER_OK;
@@ -642,9 +660,11 @@ extern "C" AetherVae* aether_vae_create(const AetherVaeConfig* cfg) {
 
 extern "C" void aether_vae_destroy(AetherVae* h) {
     if (!h) return;
-    if (h->side) hipStreamDestroy(h->side);
+    for (int k = 0; k < 3; ++k) {
+        if (h->side[k]) hipStreamDestroy(h->side[k]);
+        if (h->ev_join[k]) hipEventDestroy(h->ev_join[k]);
+    }
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
-    if (h->ev_join) hipEventDestroy(h->ev_join);
     delete h;
 }
 

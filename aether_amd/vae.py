@@ -620,9 +620,7 @@ class AetherVAE:
         for (y0, x0) in origins:
             groups.setdefault((min(tile_h, H - y0), min(tile_w, W - x0)), []).append((y0, x0))
         out = {}
-        # the C launch plan batches two tiles at a time when it runs two lanes (AETHER_VAE_TWO_LANES), four otherwise: the same batches here
-        gmax = 2 if (self._flags & _lib.AETHER_VAE_TWO_LANES) and len(origins) > 1 else 4
-        batches = [((th, tw), crops[i:i + gmax]) for (th, tw), crops in groups.items() for i in range(0, len(crops), gmax)]
+        batches = [((th, tw), crops[i:i + 4]) for (th, tw), crops in groups.items() for i in range(0, len(crops), 4)]      # as the C launch plan: up to four per batch
         for (th, tw), crops in batches:
             cache: Dict = {}
             pieces = []

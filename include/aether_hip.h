@@ -255,12 +255,11 @@ typedef struct AetherVaeConfig {
     float tap_reuse_max_waste;       /* padded-plane / output-plane ratio up to which the tap-reuse convolution runs (1.06) */
     int flags;                       /* AETHER_GEMM_* flags forwarded to the GEMMs | AETHER_VAE_TWO_LANES */
 } AetherVaeConfig;
-#define AETHER_VAE_TWO_LANES 256 /* flags bit 8: the spatial tiles of one encode / decode (independent of each other until the cross-fade) are batched
-                                    two at a time instead of four, and the batches are enqueued on TWO streams — the caller's and one owned by the
-                                    handle (high priority, forked from / joined to the caller's stream by events; capturable) — balanced by tile area,
-                                    so that the small launches of one batch (512-channel levels at latent resolution, GroupNorm statistics, split-K
-                                    finalizes) fill the gaps of the other.  Same kernels, same per-tile arithmetic; a batch of two tiles may take
-                                    the split-K path where a batch of four did not (another fp32 summation order in those layers).               */
+#define AETHER_VAE_TWO_LANES 256 /* flags bit 8: the batches of equally shaped spatial tiles of one encode / decode (independent of each other until the
+                                    cross-fade) are enqueued on TWO streams — the caller's and one owned by the handle (high priority, forked from / joined to
+                                    the caller's stream by events; capturable) — assigned by tile area (480x720: the four full tiles | the five edge tiles), so
+                                    that the small launches of one lane (512-channel levels at latent resolution, GroupNorm statistics, split-K finalizes)
+                                    fill the gaps of the other.  Same kernels, same batches, same arithmetic: bit-identical to the one-lane plan.           */
 
 typedef struct AetherVae AetherVae; /* opaque host-side handle: weight table + workspace bookkeeping */
 

@@ -15,7 +15,6 @@ AETHER_EPI_BIAS = 0
 AETHER_EPI_BIAS_GELU = 1
 AETHER_EPI_BIAS_GATE_RES = 2
 AETHER_GEMM_WIDE_STORE = 1
-AETHER_ATTN_ROW_STORE = 64    # attention: whole 128-byte output rows through LDS (see include/aether_hip.h)
 AETHER_ATTN_EXACT_MAX = 32    # attention: conservative path only (true-maximum shift from tile 0, a-posteriori check per tile)
 AETHER_VAE_TWO_LANES = 256    # VAE plan: tile batches of two on two streams (see include/aether_hip.h)
 AETHER_CONV_TAP_REUSE = 128   # conv: K order is (dt, dh, channel block, dw) -> the tap-reuse kernel may be used

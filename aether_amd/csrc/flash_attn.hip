@@ -82,38 +82,15 @@ AE_DEV void fa_mask_tail(f32x16 (&sc)[2], int j, int hi, int S) {
 }
 
 // epilogue: O[q][h*64 + d], d = 32dt + 8(r>>2) + 4hi + (r&3)
-// WIDE_STORE: the wave's 32 x 64 output block goes through its own 4 KiB of LDS (`stage`: the region that held its Q fragments — every tile
-// of the sweep is done, nobody else reads it) and leaves as WHOLE 128-byte rows, eight rows per store instruction.  (Round 3 stored 16-byte
-// pieces after a half-wave exchange: four instructions, a quarter of every row each; the partial-line writes showed as 1.75 x the algorithmic
-// write traffic at the memory controller — profiles/r03_dit_step_v2.md.)
-// STORE: 0 = 8-byte stores, 1 = 16-byte stores after a half-wave exchange (v_permlane32_swap), 2 = whole rows through LDS
-template <int STORE>
-AE_DEV void fa_store(const f32x16 (&o)[2], float l_run, const FlashArgs& p, int bh, int qrow, int hi, char* smem_q) {
+// WIDE_STORE: 16-byte pieces after a half-wave exchange (v_permlane32_swap) — four store instructions, each a quarter of every 128-byte row.
+// (Round 4 also built whole-row stores through the wave's idle 4 KiB of LDS, eight rows per instruction: every attention test passed, -4 % —
+// the epilogue's registers pushed the tile-pair loop from 18 to 154 spilled registers — and the SAME 110 MB of HBM writes per launch under
+// rocprofv3 (92.6 MB of O): L2 merges the quarter rows before they leave.  Deleted; profiles/r04_attn_store_ab.txt.)
+template <bool WIDE_STORE>
+AE_DEV void fa_store(const f32x16 (&o)[2], float l_run, const FlashArgs& p, int bh, int qrow, int hi) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     const int b = bh / p.H, h = bh - b * p.H;
-    if (STORE == 2) {
-        const int lane = threadIdx.x & 63, l32 = lane & 31;
-        char* const stage = smem_q + (threadIdx.x >> 6) * 4096;
-        // LDS row = query row of the wave (128 bytes); 16-byte chunk c of row r sits at chunk position c ^ (r & 7)
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const uint2 w = make_uint2(pack_bf16x2(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv), pack_bf16x2(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv));
-                *(uint2*)(stage + l32 * 128 + (((4 * dt + g) ^ (l32 & 7)) << 4) + 8 * hi) = w;
-            }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave's own writes have landed (wave-private region: no barrier needed)
-        const int q0 = qrow - l32;                               // first query row of this wave
-        const int ch = lane & 7;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int r = 8 * it + (lane >> 3);
-            const uint4 v = *(const uint4*)(stage + r * 128 + ((ch ^ (r & 7)) << 4));
-            if (q0 + r < p.S) *(uint4*)(p.O + ((size_t)b * p.S + q0 + r) * (size_t)(p.H * FA_D) + h * FA_D + ch * 8) = v;
-        }
-        return;
-    }
     const bool q_ok = qrow < p.S;
     const int qrow_c = min(qrow, p.S - 1);
     bf16_t* orow = p.O + ((size_t)b * p.S + qrow_c) * (size_t)(p.H * FA_D) + h * FA_D;
@@ -125,7 +102,7 @@ AE_DEV void fa_store(const f32x16 (&o)[2], float l_run, const FlashArgs& p, int 
             pk[g][0] = pack_bf16x2(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
             pk[g][1] = pack_bf16x2(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
         }
-        if (STORE == 1) {
+        if (WIDE_STORE) {
 #pragma unroll
             for (int g = 0; g < 4; g += 2) {
                 auto r0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
@@ -209,7 +186,7 @@ AE_DEV float fa_exp_tile(const f32x16 (&sc)[2], u32x4 (&pf)[2][2]) {
 // cycles for 16 MFMAs + one tile's soft-max) with the Q fragments in 16 registers (the optimistic sweep has no shift vector to hold).
 // The generic tile takes its row sums by v_dot2c_f32_bf16 from the rounded P pairs (fa_exp_pair<true>: +4 % there — it frees the registers
 // the four add chains spill), the tile-pair loop by plain adds (dot2 measured -2 % inside it).
-template <int STORE, bool PAIR>
+template <bool WIDE_STORE, bool PAIR>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))   // <= 128 VGPRs, 16 waves per CU
 void flash_attn_fwd_kernel(FlashArgs p) {
     // 2 x (K tile + V^T tile) + this workgroup's Q fragments (4 KiB per wave, lane-linear: conflict-free ds_read_b128).  Q lives in
@@ -489,7 +466,7 @@ void flash_attn_fwd_kernel(FlashArgs p) {
         tile(nkv - 1, std::true_type{});
     }
 
-    fa_store<STORE>(o, l_run, p, bh, qrow, hi, smem + 2 * FA_BUF);
+    fa_store<WIDE_STORE>(o, l_run, p, bh, qrow, hi);
 }
 
 
@@ -510,16 +487,12 @@ extern "C" int aether_flash_attn_fwd(const void* Qh, const void* Kh, const void*
     p.nqb = (S + FA_QBLK - 1) / FA_QBLK;
     p.nwg = p.nqb * B * H;
     hipStream_t s = (hipStream_t)stream;
-    const bool pair = !(flags & AETHER_ATTN_EXACT_MAX);
-    const int store = !(flags & AETHER_GEMM_WIDE_STORE) ? 0 : (flags & AETHER_ATTN_ROW_STORE) ? 2 : 1;
+    const bool wide = (flags & AETHER_GEMM_WIDE_STORE) != 0, pair = !(flags & AETHER_ATTN_EXACT_MAX);
     // ONE launch of 256-row workgroups (512 resident slots: 2 x 8 waves per CU at 128 VGPRs)
     const dim3 grid(p.nwg), block(512);
-#define FA_LAUNCH(ST)                                                                                       \
-    do {                                                                                                    \
-        if (pair) hipLaunchKernelGGL((flash_attn_fwd_kernel<ST, true>), grid, block, 0, s, p);              \
-        else hipLaunchKernelGGL((flash_attn_fwd_kernel<ST, false>), grid, block, 0, s, p);                  \
-    } while (0)
-    if (store == 2) FA_LAUNCH(2); else if (store == 1) FA_LAUNCH(1); else FA_LAUNCH(0);
-#undef FA_LAUNCH
+    if (wide && pair) hipLaunchKernelGGL((flash_attn_fwd_kernel<true, true>), grid, block, 0, s, p);
+    else if (wide) hipLaunchKernelGGL((flash_attn_fwd_kernel<true, false>), grid, block, 0, s, p);
+    else if (pair) hipLaunchKernelGGL((flash_attn_fwd_kernel<false, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((flash_attn_fwd_kernel<false, false>), grid, block, 0, s, p);
     return aether_check_launch("flash_attn_fwd");
 }

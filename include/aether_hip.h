@@ -106,9 +106,6 @@ int aether_qk_norm_rope(const void* qkv, int B, int S, int H, int n_text, const 
 #define AETHER_ATTN_EXACT_MAX 32  /* flags bit 5: conservative path only: no shift-0 sweep — every row's shift is a true score maximum from
                                      its first tile on (generic tiles with the a-posteriori check); data-independent cost           */
 
-#define AETHER_ATTN_ROW_STORE 64  /* flags bit 6 (with AETHER_GEMM_WIDE_STORE): the 32 x 64 output block of a wave leaves through its LDS region as WHOLE
-                                     128-byte rows (eight rows per store instruction) instead of 16-byte pieces after a half-wave exchange          */
-
 /* Non-causal flash attention, head_dim 64: O[b,s,h*64+d] = softmax_2(Qh·Khᵀ)·V where softmax_2 uses base 2, i.e.
  * Qh must carry softmax_scale·log2(e) (see aether_qk_norm_rope).  Replaces F.scaled_dot_product_attention in
  * CogVideoXAttnProcessor2_0.  Qh,Kh [B,H,S,64], Vt [B,H,64,Spad], O bf16 [B,S,H*64].
@@ -120,7 +117,7 @@ int aether_qk_norm_rope(const void* qkv, int B, int S, int H, int n_text, const 
  * the same with shift 0 for the whole sweep in a two-tile software pipeline; finished rows whose sum is not in [2^-100, inf) or
  * whose accumulators are not finite make the WORKGROUP redo its sweep on the conservative path.  Either way the results are those
  * of an exact fp32 soft-max; only speed depends on the data (|log2-domain score| > 100 is needed to leave the fast path).
- * flags: AETHER_GEMM_WIDE_STORE (16-byte epilogue stores), AETHER_ATTN_EXACT_MAX, AETHER_ATTN_ROW_STORE. */
+ * flags: AETHER_GEMM_WIDE_STORE (16-byte epilogue stores), AETHER_ATTN_EXACT_MAX. */
 int aether_flash_attn_fwd(const void* Qh, const void* Kh, const void* Vt, void* O, int B, int H, int S, int Spad, int flags, void* stream);
 
 /* Element-wise tail of one denoise step in ONE pass (aetherv1_pipeline_cogvideox.py:876-916): fp32 cast of the noise prediction (P:877),

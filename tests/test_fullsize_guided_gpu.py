@@ -165,7 +165,8 @@ def test_reconstruction_trajectory_ten_steps(cuda, modules):
     fin = fc.metrics(pipe._final_latents.cpu().float()[..., ::2, ::2], fc.from_bf16_bits(z["final_latents_s2_bits"]).float())
     print("\n[fullsize] 10-step reconstruction trajectory, latents rel-L2 vs fp32 oracle after each step: " + " ".join(f"{e:.2e}" for e in errs)
           + f"; final (every 2nd pixel): rel-L2 {fin['rel_l2']:.3e}  L-inf {100 * fin['linf_rel']:.2f} % of max")
-    assert max(errs) <= 3.0e-2 and fin["rel_l2"] <= 3.0e-2 and fin["linf_rel"] <= 0.06, (errs, fin)
+    # measured: 1.8e-3 after step 0, growing like the square root of the step count to 9.5e-3 after step 9; final 9.49e-3 / 1.85 % (bounds ~1.3 x)
+    assert max(errs) <= 1.25e-2 and fin["rel_l2"] <= 1.25e-2 and fin["linf_rel"] <= 0.025, (errs, fin)
 
 
 def _trajectory(pipe, steps, keep=None):
@@ -188,7 +189,12 @@ def _trajectory(pipe, steps, keep=None):
         def step_fused(self, *a, **kw):
             return self._rec(super().step_fused(*a, **kw))
 
+    # the pipeline decides from `step`'s SIGNATURE whether to hand it the generator (prepare_extra_step_kwargs, P:801): a bare (*a, **kw) wrapper
+    # would silently send every scheduler draw to the global generator
+    import inspect
+    Spy.step.__signature__ = inspect.signature(CogVideoXDPMScheduler.step)
     pipe.scheduler = Spy()
+    assert "generator" in pipe.prepare_extra_step_kwargs(torch.Generator(), 0.0)
     out = pipe(task="reconstruction", video=fc.clip_video(), height=fc.HEIGHT, width=fc.WIDTH, num_frames=fc.FRAMES, fps=12,
                num_inference_steps=steps, generator=torch.Generator().manual_seed(fc.CLIP_SEED))
     return out, rec

@@ -728,7 +728,7 @@ class AetherVAE:
     def decode_pair(self, z_a: torch.Tensor, z_b: torch.Tensor):
         """`(decode(z_a).sample, decode(z_b).sample)` — the pipeline's two final decodes (rgb and disparity latents, P:931,936).
         With the two-lane launch plan (AETHER_VAE_TWO_LANES, the default) every decode already runs its tile batches on two streams, and the pair is
-        simply the two calls one after the other: 0.768 s per pair at 41 x 480 x 720, where two ONE-lane decodes on two streams took 0.765 s and
+        simply the two calls one after the other: 0.74-0.78 s per pair at 41 x 480 x 720, where two ONE-lane decodes on two streams took 0.765 s and
         two TWO-lane decodes on two streams (four streams in all) 0.836 s (profiles/r04_vae_lanes_ab.json) — and no second workspace.
         Without the lanes flag the two decodes are enqueued on two HIP streams over a twin launch context (a second C handle over the same packed
         weights with a workspace and hipGraphs of its own: + 28.8 GB).  Same kernels, same order within each decode either way: results are

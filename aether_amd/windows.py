@@ -195,7 +195,7 @@ def run_windows_merged(call_window: Callable[[int], "object"], starts: Sequence[
                 i = j * world + r
                 if i >= len(starts):
                     continue
-                a, b, c, flag = torch.split(g, sizes + [1])
+                a, b, c, _valid = torch.split(g, sizes + [1])
                 merge(i, a.view(shapes[0]), b.view(shapes[1]), c.view(shapes[2]))
         if side is not None:
             side.wait_stream(torch.cuda.current_stream(dev))
@@ -205,8 +205,6 @@ def run_windows_merged(call_window: Callable[[int], "object"], starts: Sequence[
                 g.record_stream(side)
         else:
             merge_round()
-    if dist is not None and collective:
-        pass
     if rank != 0:
         if timings is not None:
             timings["windows_and_gather"] = time.perf_counter() - t_begin

@@ -210,7 +210,7 @@ def vae_leg(dev, reps=3):
     torch.cuda.synchronize()
     sec = (time.perf_counter() - t0) / reps
     out["decode_pair"] = {"seconds": sec, "algorithmic_tflop": 2 * 369.0, "tflops": 2 * 369.0 / sec, "mfma_frac": 2 * 369.0 / sec / MFMA_PEAK_TFLOPS,
-                                      "note": "both decodes of one pipeline call (two-lane launch plan: tile batches of two on two HIP streams inside each decode)"}
+                                      "note": "both decodes of one pipeline call (two-lane launch plan: the tile batches of each decode on two HIP streams)"}
     del vae
     torch.cuda.empty_cache()
     return out

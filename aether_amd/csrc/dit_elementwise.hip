@@ -48,15 +48,28 @@ __global__ __launch_bounds__(256) void layernorm_modulate_kernel(LnArgs p, int b
         *(f32x4*)&vec[3][i] = shift ? *(const f32x4*)(shift + i) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
-    for (int row = row0 + wave; row < min(row0 + LN_RPB, seg1); row += 4) {
-        const bf16_t* xr = p.x + (size_t)row * p.ldx;
+    // The wave's rows are software-pipelined by one: the 16-byte loads of row r + 4 are issued BEFORE row r is reduced and stored (x and y are
+    // not declared disjoint, so the compiler may not move the next row's loads above this row's stores by itself — each wave had one row in
+    // flight, 6 KiB, for a third of its time).  The next row stays packed (bf16) until it becomes the current one: 24 registers, not 48.
+    const int rend = min(row0 + LN_RPB, seg1);
+    u16x8 cur[NCH], nxt[NCH];
+    int row = row0 + wave;
+    if (row < rend) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) cur[c] = *(const u16x8*)(p.x + (size_t)row * p.ldx + c * 512 + lane * 8);
+    }
+    for (; row < rend; row += 4) {
+        const bool has_next = row + 4 < rend;
+        if (has_next) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) nxt[c] = *(const u16x8*)(p.x + (size_t)(row + 4) * p.ldx + c * 512 + lane * 8);
+        }
         float v[NCH][8];
         float sum = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const u16x8 raw = *(const u16x8*)(xr + c * 512 + lane * 8);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { v[c][e] = bf16_bits_to_f32(raw[e]); sum += v[c][e]; }
+            for (int e = 0; e < 8; ++e) { v[c][e] = bf16_bits_to_f32(cur[c][e]); sum += v[c][e]; }
         }
         const float mean = wave_sum(sum) / (float)p.D;
         float sq = 0.f;
@@ -90,6 +103,10 @@ __global__ __launch_bounds__(256) void layernorm_modulate_kernel(LnArgs p, int b
             uint4 out = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]),
                                    pack_bf16x2(o[6], o[7]));
             *(uint4*)(yr + d0) = out;
+        }
+        if (has_next) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) cur[c] = nxt[c];
         }
     }
 }

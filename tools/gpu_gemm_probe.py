@@ -12,7 +12,7 @@ from aether_amd import ops  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--flags", type=int, default=5)
+    ap.add_argument("--flags", type=int, default=1)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--M", type=int, default=15076)
     ap.add_argument("--N", type=int, default=12288)

@@ -64,7 +64,7 @@ def main():
         out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
         R = rnd(M, N) if epi == ops.AETHER_EPI_BIAS_GATE_RES else None
         gate = rnd(1, 2 * N, dtype=torch.float32) if R is not None else None
-        variants = ((1 | 4, True), (1 | 4 | 1024, True), (1 | 8, True))     # ping-pong (8 waves), four-wave in-wave-interleaved loop, ping-pong with two k-steps per slot
+        variants = ((1, True), (1, False))     # the ping-pong loop with and without the split-K tail launch
         kw = dict(R=R, gate_vid=gate[:, :N], gate_txt=gate[:, N:], rows_per_batch=M, n_text=226) if R is not None else {}
         times = {v: [] for v in variants}
         for _ in range(3):                      # interleaved rounds (guide rule 24): median reported

@@ -301,12 +301,18 @@ class AetherVAE:
         if need == 0:
             raise RuntimeError("aether_vae_workspace_bytes: " + self._lib.aether_last_error().decode())
         if self._workspace is None or self._workspace.numel() < need:
-            # one workspace for both directions, grown to the larger need (nothing in it persists from call to call except the tiny
-            # tap-offset tables, which the library regenerates when the pointer changes)
+            # one workspace for both directions (nothing in it persists from call to call except the tiny tap-offset tables, which the library
+            # regenerates when the pointer changes), sized at once for this call AND for the mirror call of the other direction — the decode of
+            # the latent this encode produces, or the encode of the clip this decode produces — so that a pipeline's first encode is not followed
+            # by a re-allocation (and the loss of its captured graph) at the first decode
+            down = 2 ** (len(self.config.block_out_channels) - 1)
+            ct = self.config.temporal_compression_ratio
+            mirror = ((T - 1) * ct + 1, H * down, W * down) if decode else ((T - 1) // ct + 1, H // down, W // down)
+            other = self._lib.aether_vae_workspace_bytes(self._handle, int(not decode), *mirror, int(self.use_tiling)) if min(mirror) > 0 else 0
             self._workspace = None
             self._graphs.clear()
             torch.cuda.empty_cache()
-            self._ws_bytes = max(int(need), 0 if self._ws_bytes is None else self._ws_bytes) + (1 << 20)
+            self._ws_bytes = max(int(need), int(other), 0 if self._ws_bytes is None else self._ws_bytes) + (1 << 20)
             self._workspace = torch.empty(self._ws_bytes, dtype=torch.uint8, device=self.device)
         fn = self._lib.aether_vae_decode if decode else self._lib.aether_vae_encode
         what = "aether_vae_decode" if decode else "aether_vae_encode"

@@ -20,91 +20,108 @@ struct LnArgs {
     int mod_bstride, rows_per_batch, n_text;
 };
 
-// One workgroup = 16 rows of ONE (batch item, row type) segment — text rows [0, n_text) or video rows [n_text, S) of a batch item
-// share their modulation vectors — so the four fp32 vectors a row needs (LayerNorm weight / bias, AdaLN scale / shift: 48 KiB at
-// D = 3072, EIGHT times the 6 KiB of the row itself) are staged in LDS once per workgroup instead of being re-read from L2 by
-// every row (round 1: 1.5 GB of L2 traffic per launch against 185 MB of HBM traffic — the kernel sat on the L2 roof at 3.9 TB/s).
-// A wave owns one row at a time (the row lives in registers); the arithmetic and its order are unchanged.
-constexpr int LN_RPB = 16;
+// Rows are handed out in BLOCKS of 4 (one row per wave) that never straddle a (batch item, row type) segment — text rows [0, n_text) or video
+// rows [n_text, S) of a batch item share their modulation vectors.  The grid is PERSISTENT (at most three workgroups per CU: 48 KiB of LDS each
+// at D = 3072): workgroup g walks blocks g, g + G, g + 2G, ... and stages the four fp32 vectors a row needs (LayerNorm weight / bias, AdaLN
+// scale / shift: 48 KiB, EIGHT times the 6 KiB of the row itself) in LDS only when the segment changes — once or twice per launch — instead
+// of re-reading them from L2 for every row (round 1: 1.5 GB of L2 traffic per launch, the kernel sat on the L2 roof at 3.9 TB/s) or once per
+// 16 rows (rounds 2-3; 943 such workgroups on 768 resident slots also left a 23 % second round).  A wave owns one row at a time (the row
+// lives in registers), software-pipelined by one block; the arithmetic and its order are unchanged.
+constexpr int LN_RPB = 4;
 template <int NCH>  // D = NCH * 512
-__global__ __launch_bounds__(256) void layernorm_modulate_kernel(LnArgs p, int blk_txt, int blk_vid) {
+__global__ __launch_bounds__(256) void layernorm_modulate_kernel(LnArgs p, int blk_txt, int blk_vid, int nblocks) {
     __shared__ __attribute__((aligned(16))) float vec[4][NCH * 512];     // w, b, scale, shift
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int per_batch = blk_txt + blk_vid;
-    const int bidx = blockIdx.x / per_batch, r = blockIdx.x - bidx * per_batch;
-    const bool txt = r < blk_txt;
-    const int seg0 = bidx * p.rows_per_batch + (txt ? 0 : p.n_text);
-    const int seg1 = min(p.rows, bidx * p.rows_per_batch + (txt ? p.n_text : p.rows_per_batch));
-    const int row0 = seg0 + (txt ? r : r - blk_txt) * LN_RPB;
-    const float* shift = nullptr; const float* scale = nullptr;
-    if (p.shift_vid != nullptr) {
-        shift = (txt ? p.shift_txt : p.shift_vid) + (size_t)bidx * p.mod_bstride;
-        scale = (txt ? p.scale_txt : p.scale_vid) + (size_t)bidx * p.mod_bstride;
-    }
-    for (int i = threadIdx.x * 4; i < NCH * 512; i += 1024) {
-        *(f32x4*)&vec[0][i] = p.w ? *(const f32x4*)(p.w + i) : f32x4{1.f, 1.f, 1.f, 1.f};
-        *(f32x4*)&vec[1][i] = p.w ? *(const f32x4*)(p.b + i) : f32x4{0.f, 0.f, 0.f, 0.f};
-        *(f32x4*)&vec[2][i] = scale ? *(const f32x4*)(scale + i) : f32x4{0.f, 0.f, 0.f, 0.f};
-        *(f32x4*)&vec[3][i] = shift ? *(const f32x4*)(shift + i) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    __syncthreads();
-    // The wave's rows are software-pipelined by one: the 16-byte loads of row r + 4 are issued BEFORE row r is reduced and stored (x and y are
-    // not declared disjoint, so the compiler may not move the next row's loads above this row's stores by itself — each wave had one row in
-    // flight, 6 KiB, for a third of its time).  The next row stays packed (bf16) until it becomes the current one: 24 registers, not 48.
-    const int rend = min(row0 + LN_RPB, seg1);
+    // block id -> (segment key, row of this wave or -1)
+    auto locate = [&](int blk, int& key) -> int {
+        const int bidx = blk / per_batch, r = blk - bidx * per_batch;
+        const bool txt = r < blk_txt;
+        key = 2 * bidx + (txt ? 1 : 0);
+        const int seg0 = bidx * p.rows_per_batch + (txt ? 0 : p.n_text);
+        const int seg1 = min(p.rows, bidx * p.rows_per_batch + (txt ? p.n_text : p.rows_per_batch));
+        const int row = seg0 + (txt ? r : r - blk_txt) * LN_RPB + wave;
+        return row < seg1 ? row : -1;
+    };
+    auto load_row = [&](int row, u16x8 (&dst)[NCH]) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) dst[c] = *(const u16x8*)(p.x + (size_t)row * p.ldx + c * 512 + lane * 8);
+    };
+    int staged = -1;
+    bool mod = false;
     u16x8 cur[NCH], nxt[NCH];
-    int row = row0 + wave;
-    if (row < rend) {
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) cur[c] = *(const u16x8*)(p.x + (size_t)row * p.ldx + c * 512 + lane * 8);
-    }
-    for (; row < rend; row += 4) {
-        const bool has_next = row + 4 < rend;
-        if (has_next) {
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) nxt[c] = *(const u16x8*)(p.x + (size_t)(row + 4) * p.ldx + c * 512 + lane * 8);
-        }
-        float v[NCH][8];
-        float sum = 0.f;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { v[c][e] = bf16_bits_to_f32(cur[c][e]); sum += v[c][e]; }
-        }
-        const float mean = wave_sum(sum) / (float)p.D;
-        float sq = 0.f;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; sq += d * d; }
-        const float rstd = rsqrtf(wave_sum(sq) / (float)p.D + p.eps);
-        bf16_t* yr = p.y + (size_t)row * p.ldy;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const int d0 = c * 512 + lane * 8;
-            float o[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (v[c][e] - mean) * rstd;
-            if (p.w != nullptr) {
-                const f32x4 w0 = *(const f32x4*)&vec[0][d0], w1 = *(const f32x4*)&vec[0][d0 + 4];
-                const f32x4 b0 = *(const f32x4*)&vec[1][d0], b1 = *(const f32x4*)&vec[1][d0 + 4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { o[e] = o[e] * w0[e] + b0[e]; o[e + 4] = o[e + 4] * w1[e] + b1[e]; }
+    int key = 0, blk = blockIdx.x;
+    int row = blk < nblocks ? locate(blk, key) : -1;
+    if (row >= 0) load_row(row, cur);
+    for (; blk < nblocks; blk += gridDim.x) {
+        // the next block's row is requested BEFORE this one is reduced and stored (x and y are not declared disjoint: the compiler may not
+        // hoist the loads above the stores by itself); it stays packed (bf16) until it becomes the current one
+        int key_next = 0;
+        const int row_next = blk + (int)gridDim.x < nblocks ? locate(blk + gridDim.x, key_next) : -1;
+        if (row_next >= 0) load_row(row_next, nxt);
+        if (key != staged) {                                  // workgroup-uniform: every wave of the workgroup is at the same block
+            __syncthreads();                                  // (all waves are done with the previous segment's vectors)
+            const int bidx = key >> 1;
+            const bool txt = key & 1;
+            const float* shift = nullptr; const float* scale = nullptr;
+            if (p.shift_vid != nullptr) {
+                shift = (txt ? p.shift_txt : p.shift_vid) + (size_t)bidx * p.mod_bstride;
+                scale = (txt ? p.scale_txt : p.scale_vid) + (size_t)bidx * p.mod_bstride;
             }
-            if (shift != nullptr) {
-                const f32x4 s0 = *(const f32x4*)&vec[2][d0], s1 = *(const f32x4*)&vec[2][d0 + 4];
-                const f32x4 h0 = *(const f32x4*)&vec[3][d0], h1 = *(const f32x4*)&vec[3][d0 + 4];
+            mod = shift != nullptr;
+            for (int i = threadIdx.x * 4; i < NCH * 512; i += 1024) {
+                *(f32x4*)&vec[0][i] = p.w ? *(const f32x4*)(p.w + i) : f32x4{1.f, 1.f, 1.f, 1.f};
+                *(f32x4*)&vec[1][i] = p.w ? *(const f32x4*)(p.b + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+                *(f32x4*)&vec[2][i] = scale ? *(const f32x4*)(scale + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+                *(f32x4*)&vec[3][i] = shift ? *(const f32x4*)(shift + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            __syncthreads();
+            staged = key;
+        }
+        if (row >= 0) {
+            float v[NCH][8];
+            float sum = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    o[e] = o[e] * (1.0f + s0[e]) + h0[e];
-                    o[e + 4] = o[e + 4] * (1.0f + s1[e]) + h1[e];
+            for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { v[c][e] = bf16_bits_to_f32(cur[c][e]); sum += v[c][e]; }
+            }
+            const float mean = wave_sum(sum) / (float)p.D;
+            float sq = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; sq += d * d; }
+            const float rstd = rsqrtf(wave_sum(sq) / (float)p.D + p.eps);
+            bf16_t* yr = p.y + (size_t)row * p.ldy;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int d0 = c * 512 + lane * 8;
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (v[c][e] - mean) * rstd;
+                if (p.w != nullptr) {
+                    const f32x4 w0 = *(const f32x4*)&vec[0][d0], w1 = *(const f32x4*)&vec[0][d0 + 4];
+                    const f32x4 b0 = *(const f32x4*)&vec[1][d0], b1 = *(const f32x4*)&vec[1][d0 + 4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { o[e] = o[e] * w0[e] + b0[e]; o[e + 4] = o[e + 4] * w1[e] + b1[e]; }
                 }
+                if (mod) {
+                    const f32x4 s0 = *(const f32x4*)&vec[2][d0], s1 = *(const f32x4*)&vec[2][d0 + 4];
+                    const f32x4 h0 = *(const f32x4*)&vec[3][d0], h1 = *(const f32x4*)&vec[3][d0 + 4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o[e] = o[e] * (1.0f + s0[e]) + h0[e];
+                        o[e + 4] = o[e + 4] * (1.0f + s1[e]) + h1[e];
+                    }
+                }
+                uint4 out = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]),
+                                       pack_bf16x2(o[6], o[7]));
+                *(uint4*)(yr + d0) = out;
             }
-            uint4 out = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]),
-                                   pack_bf16x2(o[6], o[7]));
-            *(uint4*)(yr + d0) = out;
         }
-        if (has_next) {
+        row = row_next; key = key_next;
+        if (row_next >= 0) {
 #pragma unroll
             for (int c = 0; c < NCH; ++c) cur[c] = nxt[c];
         }
@@ -323,14 +340,16 @@ extern "C" int aether_layernorm_modulate(const void* x, int ldx, void* y, int ld
     if (nmod != 0 && nmod != 4) return aether_set_error(AETHER_ERR_ARG, "layernorm: give all four modulation vectors or none");
     LnArgs p{(const bf16_t*)x, ldx, (bf16_t*)y, ldy, rows, D, eps, w, b, shift_vid, scale_vid, shift_txt, scale_txt,
              mod_bstride, rows_per_batch > 0 ? rows_per_batch : rows, n_text};
-    // workgroups never straddle a (batch item, row type) segment: per batch item ceil(n_text / 16) + ceil((S - n_text) / 16)
+    // 4-row blocks never straddle a (batch item, row type) segment: per batch item ceil(n_text / 4) + ceil((S - n_text) / 4)
     const int S = p.rows_per_batch, nb = (rows + S - 1) / S;
     const int nt = (nmod == 4) ? std::min(std::max(n_text, 0), S) : 0;     // without modulation the whole batch item is one segment
     p.n_text = nt;
     const int blk_txt = (nt + LN_RPB - 1) / LN_RPB, blk_vid = (S - nt + LN_RPB - 1) / LN_RPB;
-    dim3 grid(nb * (blk_txt + blk_vid)), block(256);
+    const int nblocks = nb * (blk_txt + blk_vid);
+    const int resident = 256 * std::max(1, std::min(8, (160 * 1024) / (4 * D * 4)));          // workgroups the chip holds at once (LDS: 16 D bytes each)
+    dim3 grid(std::min(nblocks, resident)), block(256);
     switch (D / 512) {
-#define LN_CASE(n) case n: hipLaunchKernelGGL((layernorm_modulate_kernel<n>), grid, block, 0, AE_STREAM, p, blk_txt, blk_vid); break;
+#define LN_CASE(n) case n: hipLaunchKernelGGL((layernorm_modulate_kernel<n>), grid, block, 0, AE_STREAM, p, blk_txt, blk_vid, nblocks); break;
         LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8)
 #undef LN_CASE
     }

@@ -219,4 +219,7 @@ def test_headline_reconstruction_fifty_steps(cuda, modules):
     print("\n[fullsize] HEADLINE config, 50-step reconstruction: latents rel-L2 vs fp32 oracle after steps " + ", ".join(f"{i}: {e:.2e}" for i, e in zip(kept, errs))
           + f"; final (every 2nd pixel): rel-L2 {fin['rel_l2']:.3e}  L-inf {100 * fin['linf_rel']:.2f} % of max; rgb PSNR {p_rgb:.1f} dB; disparity rel-L2 {m_disp['rel_l2']:.3e}"
           + f" ({meta['seconds_cpu_total']:.0f} s of CPU offline)")
-    assert np.isfinite(out.rgb).all() and fin["rel_l2"] <= 0.12 and p_rgb >= 25.0, (errs, fin, p_rgb)      # loose until measured; tightened in DESIGN §2 / here
+    # measured on MI355X: 7.4e-4 after step 0, 5.9e-3 after 10 steps, 9.2e-3 after 20, 1.03e-2 after 35, 1.35e-2 after 50; final 1.354e-2 / 2.74 %;
+    # rgb 36.9 dB; disparity 2.58e-2 (bounds ~1.3 x)
+    assert np.isfinite(out.rgb).all() and max(errs) <= 1.8e-2 and fin["rel_l2"] <= 1.8e-2 and fin["linf_rel"] <= 0.036, (errs, fin)
+    assert p_rgb >= 34.6 and m_disp["rel_l2"] <= 3.4e-2, (p_rgb, m_disp)

@@ -163,15 +163,21 @@ def mfma_power_cap_leg():
     return res
 
 
-def vae_leg(dev, reps=3):
-    """VAE encode of a 41x480x720 clip and decode of its 11x60x90 latent exactly as the pipeline calls them (tiling + slicing on):
-    seconds (HIP events on the launch stream), algorithmic TFLOP with the reference's tiling (SURVEY.md §8d: 175 / 369) and the
-    fraction of the 2.5 PF/s dense bf16 MFMA peak."""
+def make_vae(dev):
+    """The ONE VAE of the process (what an application holds): built and its workspace reserved right after the transformer, before the timed
+    legs churn the heap — the VAE leg and the clip legs share it, as a pipeline shares its VAE across calls."""
     from aether_amd.vae import AetherVAE
 
     vae = AetherVAE(device=dev).init_random_weights(1)
     vae.enable_slicing()
     vae.enable_tiling()
+    return vae
+
+
+def vae_leg(dev, vae, reps=3):
+    """VAE encode of a 41x480x720 clip and decode of its 11x60x90 latent exactly as the pipeline calls them (tiling + slicing on):
+    seconds (HIP events on the launch stream), algorithmic TFLOP with the reference's tiling (SURVEY.md §8d: 175 / 369) and the
+    fraction of the 2.5 PF/s dense bf16 MFMA peak."""
     g = torch.Generator(device=dev).manual_seed(0)
     x = (torch.rand(1, 3, 41, 480, 720, generator=g, device=dev) * 2 - 1).to(torch.bfloat16)
     z = torch.randn(1, 16, 11, 60, 90, generator=g, device=dev).to(torch.bfloat16)
@@ -211,12 +217,10 @@ def vae_leg(dev, reps=3):
     sec = (time.perf_counter() - t0) / reps
     out["decode_pair"] = {"seconds": sec, "algorithmic_tflop": 2 * 369.0, "tflops": 2 * 369.0 / sec, "mfma_frac": 2 * 369.0 / sec / MFMA_PEAK_TFLOPS,
                                       "note": "both decodes of one pipeline call (two-lane launch plan: the tile batches of each decode on two HIP streams)"}
-    del vae
-    torch.cuda.empty_cache()
     return out
 
 
-def clip_wall_clock(transformer, dev, steps):
+def clip_wall_clock(transformer, dev, steps, vae):
     """Wall-clock of ONE whole pipeline call (BASELINE metric, second half): reconstruction of a synthetic 41x480x720 clip
     through the drop-in entry point — VAE encode (tiled, 9 tiles x 5 frame chunks), `steps` denoise steps, two VAE decodes,
     D2H of rgb/disparity/raymap — random-init weights, device generator seeded like scripts/demo.py:629."""
@@ -224,11 +228,7 @@ def clip_wall_clock(transformer, dev, steps):
 
     from aether.pipelines.aetherv1_pipeline_cogvideox import AetherV1PipelineCogVideoX
     from aether_amd.scheduler import CogVideoXDPMScheduler
-    from aether_amd.vae import AetherVAE
 
-    vae = AetherVAE(device=dev).init_random_weights(1)
-    vae.enable_slicing()
-    vae.enable_tiling()
     g = torch.Generator().manual_seed(0)
     prompt = (torch.randn(1, 226, 4096, generator=g) * 0.1).to(torch.bfloat16)
     pipe = AetherV1PipelineCogVideoX(tokenizer=None, text_encoder=None, vae=vae, scheduler=CogVideoXDPMScheduler(),
@@ -579,11 +579,13 @@ def main():
         }
         line.update({k: v for k, v in multi.items() if v is not None})
         if world == 1 and not args.no_extra_legs:
-            # The VAE leg runs FIRST among the extra legs: its 9 / 15 GiB workspace is then allocated in the same state as in a fresh process.
-            # (Measured in round 4: allocated after the clip and windows legs, the encode workspace landed in memory on which the SAME captured
-            # graph ran 40 % slower — 265 ms on every sample against 188-195 ms before those legs, after a re-allocation, and in a fresh process;
-            # profiles/r04_bench_vae_order.json.  Address-dependent, most likely the page size the driver could still find for a 9 GB block.)
-            line["vae"] = vae_leg(dev)
+            # ONE VAE for the process, built before the other legs churn the heap, shared by the VAE leg and the clip legs (as a pipeline shares
+            # its VAE across calls).  Measured in round 4: a VAE whose 9 / 15 GiB workspace was allocated AFTER the clip and windows legs ran the
+            # SAME captured encode graph 40 % slower on every sample (265 ms against 188-195 ms before those legs, after a re-allocation, and in a
+            # fresh process; profiles/r04_bench_vae_order.json) — address-dependent, most likely the page size the driver could still find for a
+            # multi-GB block.
+            shared_vae = make_vae(dev)
+            line["vae"] = vae_leg(dev, shared_vae)
         if world == 1 and not args.no_extra_legs:
             # The attention soft-max is exact on every path (include/aether_hip.h).  Legs, each `--steps` timed steps: the default
             # (optimistic shift-0 tile-pair sweep), the CONSERVATIVE path alone (true-maximum shift from the first tile, a-posteriori
@@ -619,7 +621,7 @@ def main():
                 cap["dominant_kernel_frac_of_random_operand_stream"] = round(ach / cap["random_operands"]["tflops"], 4)
             line["mfma_power_cap"] = cap
         if world == 1 and not args.no_clip:
-            line["clip"] = clip_wall_clock(model, dev, args.clip_steps)
+            line["clip"] = clip_wall_clock(model, dev, args.clip_steps, shared_vae if not args.no_extra_legs else make_vae(dev))
         if world == 1 and not args.no_clip and not args.no_extra_legs:
             line["windows"] = windows_leg(args)
         if world == 1 and not args.no_cpu_baseline:

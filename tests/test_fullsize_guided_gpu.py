@@ -63,9 +63,11 @@ def _guided_inputs(task):
 # 2.45 % (both branches); 2 guided steps: latents 2.20e-2 / 3.00 %, rgb 33.1 dB, disparity 4.5e-2 — guidance u + g (c - u) with g up to 4 amplifies
 # the difference of two bf16 predictions, which is why the guided trajectory sits above the un-guided one (1.03e-2 after 4 steps)
 GUIDED_BOUNDS = {
-    "prediction": dict(post_rel=1.5e-2, fwd_rel=1.9e-2, fwd_linf=0.032, lat_rel=2.9e-2, lat_linf=0.04, psnr=30.8, disp_rel=5.9e-2),
+    # the B = 2 forward must stay within the bf16 ORACLE's own distance to the fixture (profiles/r04_bf16_oracle_calibration_guided.json:
+    # prediction 1.84e-2 / 2.83 %, planning 1.84e-2 / 2.40 %): no worse than the reference dtype
+    "prediction": dict(post_rel=1.5e-2, fwd_rel=1.84e-2, fwd_linf=0.0283, lat_rel=2.9e-2, lat_linf=0.04, psnr=30.8, disp_rel=5.9e-2),
     # planning: posteriors 1.07e-2 / 1.11e-2; B = 2 forward 1.38e-2 / 1.96 %; 2 guided steps: latents 2.46e-2 / 4.00 %, rgb 32.3 dB, disparity 4.4e-2
-    "planning": dict(post_rel=1.5e-2, fwd_rel=1.8e-2, fwd_linf=0.026, lat_rel=3.2e-2, lat_linf=0.052, psnr=30.0, disp_rel=5.7e-2),
+    "planning": dict(post_rel=1.5e-2, fwd_rel=1.84e-2, fwd_linf=0.024, lat_rel=3.2e-2, lat_linf=0.052, psnr=30.0, disp_rel=5.7e-2),
 }
 
 

@@ -43,6 +43,7 @@ GUIDED_SEED = 42
 TRAJ_STEPS = 10                              # the longer reconstruction trajectory (drift against the step count: 4 -> 10)
 HEADLINE_STEPS = 50                          # BASELINE configs[1] itself: reconstruction, 50 steps
 HEADLINE_KEEP = (0, 1, 2, 3, 4, 6, 9, 14, 19, 24, 29, 34, 39, 44, 49)   # steps whose latents the 50-step fixture keeps
+GUIDED_LONG_KEEP = tuple(range(15)) + (19, 24, 29, 34, 39, 44, 49)   # steps whose latents the 50-guided-step fixture keeps
 DEC_STRIDE = 8                               # decoded pixels kept in the fixture: every 8th row / column, all frames
 
 

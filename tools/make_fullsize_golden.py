@@ -151,6 +151,71 @@ def stage_guided(dit, task):
     log(f"{task}: wrote tests/golden/fullsize_{task}.npz")
 
 
+def stage_guided_long(dit, task, steps, keep, name):
+    """BASELINE configs[2] / configs[3] at the step count BASELINE QUOTES: the whole guided call (P:690-965) with `steps` guided steps (P:827-921),
+    dynamic classifier-free guidance evaluated on the n = `steps` schedule (P:880-893) and a CPU generator (seed GUIDED_SEED), on the named inputs
+    of `stage_guided`.  2 x `steps` B = 1-equivalent 42-block fp32 forwards: ~10.5 h of CPU for 50 steps.  Because that is most of a build
+    session, the run CHECKPOINTS: after every step it rewrites <name>.partial.npz (kept-step latents every 6th row / column so far, the latents
+    of the last finished step every 2nd row / column, per-step guidance scale and noise-prediction norms) so a run that is cut short still
+    leaves a fixture of the first k steps OF THE n-STEP SCHEDULE; the complete file adds the final latents (exact bf16 bits) and the decoded
+    rgb / disparity (every 8th row / column)."""
+    import math
+    from aether_amd.scheduler import CogVideoXDPMScheduler
+    from oracle.pipeline import sample
+    case = fc.GUIDED_CASES[task]
+    vae = fc.build_oracle_vae()
+    image = fc.image_as_model_input(fc.named_image(case["image"]))
+    goal = fc.image_as_model_input(fc.named_image(case["goal"])) if case["goal"] else None
+    raymap = torch.from_numpy(fc.forward_right_raymap())[None] if case["raymap"] else None
+    sched = CogVideoXDPMScheduler()
+    sched.set_timesteps(steps)
+    ts = [int(t) for t in sched.timesteps]
+    scales = [1 + 3.0 * ((1 - math.cos(math.pi * ((steps - t) / steps) ** 5.0)) / 2) for t in ts]      # P:886-893, guidance_scale 3.0 (P:262-266)
+    out_dir = os.environ.get("AETHER_GOLDEN_PARTIAL_DIR", fc.GOLDEN_DIR)
+    partial = os.path.join(out_dir, name.replace(".npz", ".partial.npz"))
+    times, mark, step_lat, rms, mx = {}, [time.perf_counter()], {}, [], []
+    trace = {}
+
+    def meta_now(done, total=None):
+        return dict(task=task, steps=steps, steps_done=done, timesteps=ts, guidance_scales=scales, kept_steps=sorted(step_lat), inputs=case,
+                    seed=fc.GUIDED_SEED, dit_seed=fc.DIT_SEED, vae_seed=fc.VAE_SEED, step_seconds=times, seconds_cpu_total=total,
+                    threads=torch.get_num_threads(), torch=torch.__version__, noise_pred_rms=rms, noise_pred_max=mx)
+
+    def on_step(i, latents):
+        now = time.perf_counter()
+        times[f"step{i}"] = now - mark[0]
+        mark[0] = now
+        for p in trace["noise_pred"]:                                  # [2, ...] (unconditional, conditional); keep the norms, drop the tensor
+            rms.append([float(p[b].pow(2).mean().sqrt()) for b in range(p.shape[0])])
+            mx.append(float(p.abs().max()))
+        trace["noise_pred"].clear()
+        if i in keep:
+            step_lat[i] = fc.bf16_bits(latents[:, :, :, ::6, ::6])
+        kept = sorted(step_lat)
+        np.savez_compressed(partial + ".tmp.npz", step_latents_s6=np.stack([step_lat[k] for k in kept]) if kept else np.zeros(0),
+                            last_latents_s2_bits=fc.bf16_bits(latents[..., ::2, ::2]), meta=json.dumps(meta_now(i + 1)))
+        os.replace(partial + ".tmp.npz", partial)
+        log(f"{task}{steps}: step {i} (t = {ts[i]}, guidance {scales[i]:.4f}) done ({times[f'step{i}']:.1f} s); checkpoint {os.path.basename(partial)}")
+
+    trace["on_step"] = on_step
+    t0 = time.perf_counter()
+    rgb, disp, rm = sample(task, dit, vae, sched, fc.prompt_embeds(), image=image, goal=goal, raymap=raymap, height=fc.HEIGHT, width=fc.WIDTH,
+                           num_frames=fc.FRAMES, num_inference_steps=steps, generator=torch.Generator().manual_seed(fc.GUIDED_SEED),
+                           rope=fc.rope_tables(), compute_dtype=torch.float32, trace=trace)
+    total = time.perf_counter() - t0
+    s = fc.DEC_STRIDE
+    kept = sorted(step_lat)
+    cond = trace["condition_latents"]
+    meta = meta_now(steps, total)
+    meta.update(condition_sum=float(cond.double().sum()), condition_abs_sum=float(cond.double().abs().sum()))
+    np.savez_compressed(os.path.join(fc.GOLDEN_DIR, name), step_latents_s6=np.stack([step_lat[k] for k in kept]),
+                        final_latents_bits=fc.bf16_bits(trace["final_latents"]),
+                        initial_latents_sum=np.float64(trace["initial_latents"].double().sum().item()),
+                        rgb_s8=rgb[:, ::s, ::s].numpy().astype(np.float16), disparity_s8=disp[:, ::s, ::s].numpy().astype(np.float16),
+                        meta=json.dumps(meta))
+    log(f"{task}{steps}: whole guided call took {total:.1f} s; wrote tests/golden/{name}")
+
+
 def stage_traj(dit, steps=None, name="fullsize_traj.npz", with_decodes=False, keep_steps=None):
     """The reconstruction call of `stage_clip` (same clip, same seed -> same posterior sample and initial latents) with `steps` steps: per-step
     latents (every 6th row / column; all steps, or `keep_steps`) and the final latents (every 2nd) — how the drift against the fp32 oracle
@@ -220,6 +285,10 @@ def main():
     for task in ("prediction", "planning"):
         if task in stages:
             stage_guided(dit, task)
+    if "prediction50" in stages:
+        stage_guided_long(dit, "prediction", fc.HEADLINE_STEPS, set(fc.GUIDED_LONG_KEEP), "fullsize_prediction50.npz")
+    if "planning10" in stages:
+        stage_guided_long(dit, "planning", fc.TRAJ_STEPS, set(range(fc.TRAJ_STEPS)), "fullsize_planning10.npz")
     if "traj" in stages:
         stage_traj(dit)
     if "traj50" in stages:

@@ -16,13 +16,18 @@ from einops import rearrange
 @torch.no_grad()
 def sample(task, transformer, vae, scheduler, prompt_embeds, *, image=None, goal=None, video=None, raymap=None, height, width,
            num_frames, num_inference_steps=None, guidance_scale=None, use_dynamic_cfg=False, generator=None, fps=12,
-           rope=None, dtype=torch.bfloat16, device="cpu", compute_dtype=None, trace=None):
+           rope=None, dtype=torch.bfloat16, device="cpu", compute_dtype=None, trace=None, vae_device=None):
     """image/goal: [1,3,H,W] in [-1,1]; video: [F,3,H,W]; raymap: [1,F,6,h,w]. Returns (rgb, disparity, raymap) tensors.
     compute_dtype (calibration only): run the three modules in this dtype (e.g. fp32 weights) while every random draw
     and every inter-module tensor keeps the reference dtype `dtype`, so runs at different precision see the SAME noise.
     trace (fixture generation only): a dict that receives the intermediates a full-size fixture records — the video posterior,
-    `condition_latents`, every step's noise prediction, the final latents and the raw decoder outputs."""
+    `condition_latents`, every step's noise prediction, the final latents and the raw decoder outputs.
+    device / vae_device (fixture generation on an accelerator, tools/make_fullsize_golden_gpu.py): where the transformer / the VAE live; every random
+    draw is still made on the generator's device (CPU) and moved, as `randn_tensor` does (P:683), so the noise is the same on every device."""
     cd = compute_dtype or dtype
+    dev = torch.device(device)
+    vdev = torch.device(vae_device) if vae_device is not None else dev
+    on_cpu = dev.type == "cpu" and vdev.type == "cpu"
     defaults_steps = {"reconstruction": 4, "prediction": 50, "planning": 50}                        # P:257-261
     defaults_g = {"reconstruction": 1.0, "prediction": 3.0, "planning": 3.0}                        # P:262-266
     defaults_dyn = {"reconstruction": False, "prediction": True, "planning": True}                  # P:267-271
@@ -37,14 +42,14 @@ def sample(task, transformer, vae, scheduler, prompt_embeds, *, image=None, goal
     shape = (1, lat_frames, 56, height // 8, width // 8)                                              # P:536-542
 
     def enc(x):                                                                                       # P:557-576
-        dist = vae.encode(x.to(cd)).latent_dist
+        dist = vae.encode(x.to(vdev, cd)).latent_dist
         if trace is not None:
             trace.setdefault("posterior", []).append((dist.mean.float().clone(), dist.logvar.float().clone()))
-        if cd == dtype:
+        if cd == dtype and on_cpu:
             z = dist.sample(generator)
         else:   # same bf16 noise as the reference-dtype run, higher-precision mean/std
-            z = dist.mean + dist.std * torch.randn(dist.mean.shape, generator=generator, dtype=dtype).to(cd)
-        return sf * z.to(dtype).permute(0, 2, 1, 3, 4)
+            z = dist.mean + dist.std * torch.randn(dist.mean.shape, generator=generator, dtype=dtype).to(vdev, cd)
+        return (sf * z.to(dtype).permute(0, 2, 1, 3, 4)).to(dev)
 
     if image is not None:
         image_latents = enc(image.to(dtype).unsqueeze(2))
@@ -53,22 +58,22 @@ def sample(task, transformer, vae, scheduler, prompt_embeds, *, image=None, goal
     if video is not None:
         video_latents = enc(video.to(dtype).unsqueeze(0).permute(0, 2, 1, 3, 4))
     if image is not None and goal is None:                                                            # P:633-640
-        pad = torch.zeros(1, lat_frames - 1, *image_latents.shape[2:], dtype=dtype)
+        pad = torch.zeros(1, lat_frames - 1, *image_latents.shape[2:], dtype=dtype, device=dev)
         cond = torch.cat([image_latents, pad], dim=1)
     elif goal is not None:                                                                            # P:641-648
-        pad = torch.zeros(1, lat_frames - 2, *image_latents.shape[2:], dtype=dtype)
+        pad = torch.zeros(1, lat_frames - 2, *image_latents.shape[2:], dtype=dtype, device=dev)
         cond = torch.cat([image_latents, pad, goal_latents], dim=1)
     else:
         cond = video_latents
     if raymap is not None:                                                                            # P:652-670
-        raymap = raymap.to(dtype)
+        raymap = raymap.to(dev, dtype)
         if raymap.shape[1] % 4 != 0:
             raymap = torch.cat([raymap[:, : 4 - raymap.shape[1] % 4], raymap], dim=1)
         cam = rearrange(raymap, "b (n t) c h w -> b t (n c) h w", n=4)
     else:
-        cam = torch.zeros(1, lat_frames, 24, height // 8, width // 8, dtype=dtype)                    # P:672-680
+        cam = torch.zeros(1, lat_frames, 24, height // 8, width // 8, dtype=dtype, device=dev)                    # P:672-680
     cond = torch.cat([cond, cam], dim=2)                                                              # P:682
-    latents = torch.randn(shape, generator=generator, dtype=dtype) * scheduler.init_noise_sigma       # P:683-686
+    latents = torch.randn(shape, generator=generator, dtype=dtype).to(dev) * scheduler.init_noise_sigma       # P:683-686
     if trace is not None:
         trace["condition_latents"], trace["initial_latents"], trace["noise_pred"] = cond.clone(), latents.clone(), []
         on_step = trace.get("on_step")
@@ -89,8 +94,8 @@ def sample(task, transformer, vae, scheduler, prompt_embeds, *, image=None, goal
         else:
             c_in = cond
         lat_in = torch.cat([lat_in, c_in], dim=2)                                                     # P:857-859
-        pred = transformer(hidden_states=lat_in.to(cd), encoder_hidden_states=prompt_embeds.repeat(lat_in.shape[0], 1, 1).to(cd),
-                           timestep=t.expand(lat_in.shape[0]), ofs=None, image_rotary_emb=rope, return_dict=False)[0].float()
+        pred = transformer(hidden_states=lat_in.to(cd), encoder_hidden_states=prompt_embeds.repeat(lat_in.shape[0], 1, 1).to(dev, cd),
+                           timestep=t.expand(lat_in.shape[0]).to(dev), ofs=None, image_rotary_emb=rope, return_dict=False)[0].float()
         if trace is not None:
             trace["noise_pred"].append(pred.clone())
         if use_dynamic_cfg:                                                                           # P:879-893
@@ -107,10 +112,10 @@ def sample(task, transformer, vae, scheduler, prompt_embeds, *, image=None, goal
         trace["final_latents"] = latents.clone()
 
     def dec(z):                                                                                       # decode_latents
-        out = vae.decode((1 / sf * z.permute(0, 2, 1, 3, 4)).to(cd)).sample
+        out = vae.decode((1 / sf * z.permute(0, 2, 1, 3, 4)).to(vdev, cd)).sample
         if trace is not None:
             trace.setdefault("decoded", []).append(out.float().clone())
-        return out.to(dtype)
+        return out.to(dev, dtype)
 
     rgb = dec(latents[:, :, :16])                                                                     # P:925-934
     rgb = (rgb[0].permute(1, 0, 2, 3) / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).float()

@@ -216,6 +216,34 @@ def stage_guided_long(dit, task, steps, keep, name):
     log(f"{task}{steps}: whole guided call took {total:.1f} s; wrote tests/golden/{name}")
 
 
+def stage_decode_long(name):
+    """Finish a long guided fixture whose trajectory was computed elsewhere (tools/make_fullsize_golden_gpu.py stores the final latents, exact bf16
+    bits): the two final decodes of P:925-940 with the fp32 CPU oracle VAE, post-processed as `oracle.pipeline.sample` does, every 8th row / column."""
+    path = os.path.join(fc.GOLDEN_DIR, name)
+    z = dict(np.load(path))
+    meta = json.loads(str(z["meta"]))
+    vae = fc.build_oracle_vae()
+    sf = vae.config.scaling_factor
+    lat = fc.from_bf16_bits(z["final_latents_bits"])                                   # [1,11,56,60,90] bf16
+    t0 = time.perf_counter()
+
+    def dec(x):
+        with torch.no_grad():
+            return vae.decode((1 / sf * x.permute(0, 2, 1, 3, 4)).float()).sample.to(torch.bfloat16)
+
+    rgb = dec(lat[:, :, :16])
+    rgb = (rgb[0].permute(1, 0, 2, 3) / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).float()
+    log(f"{name}: rgb decode done ({time.perf_counter() - t0:.0f} s)")
+    disp = dec(lat[:, :, 16:32]).mean(dim=1)
+    disp = torch.square(disp * 0.5 + 0.5).float()[0]
+    s = fc.DEC_STRIDE
+    z["rgb_s8"], z["disparity_s8"] = rgb[:, ::s, ::s].numpy().astype(np.float16), disp[:, ::s, ::s].numpy().astype(np.float16)
+    meta.update(decoded=True, decode_seconds_cpu=time.perf_counter() - t0)
+    z["meta"] = json.dumps(meta)
+    np.savez_compressed(path, **z)
+    log(f"{name}: both decodes took {meta['decode_seconds_cpu']:.0f} s; rewrote tests/golden/{name}")
+
+
 def stage_traj(dit, steps=None, name="fullsize_traj.npz", with_decodes=False, keep_steps=None):
     """The reconstruction call of `stage_clip` (same clip, same seed -> same posterior sample and initial latents) with `steps` steps: per-step
     latents (every 6th row / column; all steps, or `keep_steps`) and the final latents (every 2nd) — how the drift against the fp32 oracle
@@ -274,6 +302,10 @@ def stage_traj(dit, steps=None, name="fullsize_traj.npz", with_decodes=False, ke
 def main():
     stages = sys.argv[1:] or ["dit", "clip"]
     torch.set_num_threads(int(os.environ.get("AETHER_GOLDEN_THREADS", os.cpu_count() or 8)))
+    if stages[0] == "decode50":                                        # decode50 <file.npz> ...: needs the VAE only
+        for name in stages[1:]:
+            stage_decode_long(name)
+        return
     log(f"building the 42-block oracle transformer (seed {fc.DIT_SEED}) ...")
     t0 = time.perf_counter()
     dit, _ = fc.build_oracle_dit()

@@ -78,8 +78,12 @@ Plan make_plan(const AetherDitConfig& c, int B, int F, int H, int W) {
 
 }  // namespace
 
+// flag bits a transformer handle understands; anything else is a caller error (flags of deleted kernel variants must not be accepted silently)
+static constexpr int kDitFlags = AETHER_GEMM_WIDE_STORE | AETHER_ATTN_EXACT_MAX;
+
 extern "C" AetherDit* aether_dit_create(const AetherDitConfig* cfg) {
     if (!cfg) { aether_set_error(AETHER_ERR_ARG, "dit_create: null config"); return nullptr; }
+    if (cfg->flags & ~kDitFlags) { aether_set_error(AETHER_ERR_ARG, "dit_create: undefined flag bits (defined: AETHER_GEMM_WIDE_STORE, AETHER_ATTN_EXACT_MAX)"); return nullptr; }
     if (cfg->head_dim != 64) { aether_set_error(AETHER_ERR_SHAPE, "dit_create: head_dim must be 64"); return nullptr; }
     const int D = cfg->num_heads * cfg->head_dim;
     if (D % 512 != 0 || D > 4096) { aether_set_error(AETHER_ERR_SHAPE, "dit_create: hidden size must be a multiple of 512, <= 4096"); return nullptr; }
@@ -121,6 +125,7 @@ extern "C" int aether_dit_set_pos_embedding(AetherDit* h, const void* table, int
 
 extern "C" int aether_dit_set_flags(AetherDit* h, int flags) {
     if (!h) return aether_set_error(AETHER_ERR_ARG, "dit_set_flags: null handle");
+    if (flags & ~kDitFlags) return aether_set_error(AETHER_ERR_ARG, "dit_set_flags: undefined flag bits (defined: AETHER_GEMM_WIDE_STORE, AETHER_ATTN_EXACT_MAX)");
     h->cfg.flags = flags;
     return AETHER_OK;
 }

@@ -649,6 +649,10 @@ int vae_run(AetherVae* h, bool decode, const void* src, int T, int H, int W, int
 
 extern "C" AetherVae* aether_vae_create(const AetherVaeConfig* cfg) {
     if (!cfg) { aether_set_error(AETHER_ERR_ARG, "vae_create: null config"); return nullptr; }
+    if (cfg->flags & ~(AETHER_GEMM_WIDE_STORE | AETHER_VAE_TWO_LANES)) {      // AETHER_CONV_TAP_REUSE is chosen per convolution by the plan (tap_reuse_max_waste), not by the caller
+        aether_set_error(AETHER_ERR_ARG, "vae_create: undefined flag bits (defined: AETHER_GEMM_WIDE_STORE, AETHER_VAE_TWO_LANES)");
+        return nullptr;
+    }
     if (cfg->num_levels < 2 || cfg->num_levels > 6 || cfg->latent_channels > 16 || cfg->layers_per_block < 1) {
         aether_set_error(AETHER_ERR_SHAPE, "vae_create: unsupported configuration");
         return nullptr;

@@ -316,7 +316,9 @@ int aether_dit_set_weight(AetherDit* h, const char* name, const void* dev_ptr);
  * 3-D sin-cos table of the actual size — the caller picks, aether_amd/transformer.py).  aether_dit_forward refuses a
  * table with fewer rows than text + video tokens (no out-of-bounds read).  (NULL, 0) unregisters. */
 int aether_dit_set_pos_embedding(AetherDit* h, const void* table, int rows);
-/* Replace the AETHER_GEMM_* / AETHER_ATTN_* flags given at creation (e.g. AETHER_ATTN_EXACT_MAX for a measurement). */
+/* Replace the flags given at creation (e.g. AETHER_ATTN_EXACT_MAX for a measurement).  aether_dit_create / aether_dit_set_flags accept
+ * AETHER_GEMM_WIDE_STORE | AETHER_ATTN_EXACT_MAX, aether_vae_create AETHER_GEMM_WIDE_STORE | AETHER_VAE_TWO_LANES; any other bit is
+ * AETHER_ERR_ARG (create: NULL + aether_last_error), so flags of kernel variants that no longer exist are refused, not ignored. */
 int aether_dit_set_flags(AetherDit* h, int flags);
 /* Bytes of scratch the forward needs for batch B and a latent grid F x H x W (latent pixels). */
 size_t aether_dit_workspace_bytes(const AetherDit* h, int B, int F, int H, int W);

@@ -35,6 +35,20 @@ def test_error_reporting_without_gpu(hip_lib):
     rc = hip_lib.aether_conv_gemm_bf16(4096, 1, 3, 4, 4, 64, 1, 2, 2, 3, 4096, 27, 4096, 64, 4096, 64, None, None, 0, None, 0, 0, None)
     assert rc == -2                                                                                   # stride must be 1 or 2
     assert hip_lib.aether_dit_create(None) is None
+    # undefined flag bits (e.g. the round-2/3 kernel-variant flags 4 | 512 that no longer exist) are refused, not ignored
+    import ctypes
+    from aether_amd import _lib
+    cfg = _lib.AetherDitConfig(num_layers=1, num_heads=8, head_dim=64, in_channels=16, out_channels=8, patch_size=2, text_dim=128, time_embed_dim=64,
+                               ff_mult=4, max_text_len=20, norm_eps=1e-5, qk_norm_eps=1e-6, use_pos_embedding=0, flags=1 | 4 | 512)
+    assert hip_lib.aether_dit_create(ctypes.byref(cfg)) is None and b"undefined flag bits" in hip_lib.aether_last_error()
+    cfg.flags = _lib.AETHER_GEMM_WIDE_STORE
+    h = hip_lib.aether_dit_create(ctypes.byref(cfg))
+    assert h is not None
+    assert hip_lib.aether_dit_set_flags(h, 2) == -1 and b"undefined flag bits" in hip_lib.aether_last_error()
+    assert hip_lib.aether_dit_set_flags(h, _lib.AETHER_GEMM_WIDE_STORE | _lib.AETHER_ATTN_EXACT_MAX) == 0
+    hip_lib.aether_dit_destroy(h)
+    vcfg = _lib.AetherVaeConfig(flags=_lib.AETHER_GEMM_WIDE_STORE | _lib.AETHER_CONV_TAP_REUSE, num_levels=4, latent_channels=16, layers_per_block=3)
+    assert hip_lib.aether_vae_create(ctypes.byref(vcfg)) is None and b"undefined flag bits" in hip_lib.aether_last_error()
 
 
 def test_product_path_never_imports_oracle():

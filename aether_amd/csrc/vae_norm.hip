@@ -1,9 +1,9 @@
 // GroupNorm / SpatialNorm3D of the CogVideoX VAE (diffusers nn.GroupNorm(32, C, eps=1e-6) and CogVideoXSpatialNorm3D,
 // reached from aether/pipelines/aetherv1_pipeline_cogvideox.py:557-618 and P:931,936).  HBM-bound by design:
-//   1. groupnorm_partial_kernel   one streaming read of x [NB, V, C]: per-block, per-channel (sum, sum of squares)
-//   2. groupnorm_finalize_kernel  adds block partials + the channels of a group in double precision (fixed order ->
-//                                 deterministic) and folds gamma/beta into a per-channel affine table
-//                                 y = x*scale[c] + shift[c]
+//   1. groupnorm_partial_kernel   one streaming read of x [NB, V, C]: per-block, per-group (sum, sum of squares) in double
+//   2. statistics tail            adds the block partials in double (fixed order -> deterministic) and folds gamma/beta into a
+//                                 per-channel affine table y = x*scale[c] + shift[c]; run by the LAST block of launch 1 (ticket
+//                                 counter) or, without a counter, by groupnorm_finalize_kernel
 //   3. spatial_cond_kernel        SpatialNorm3D only: conv_y / conv_b (1x1x1, 16 -> C) evaluated ONCE at latent
 //                                 resolution; nearest up-sampling commutes with a 1x1x1 convolution, so the full-
 //                                 resolution pass only gathers 2 x 8 floats per 16-byte piece
@@ -14,12 +14,57 @@
 
 namespace aether {
 
-// Streaming read at HBM rate needs many loads in flight: 1024 threads per workgroup, four independent 16-byte loads per thread
-// and iteration (256 workgroups x 1024 x 64 B = 16 MiB outstanding on the whole chip).
+// Statistics tail shared by the fused and the two-launch form: executed by ONE GN_PT-thread workgroup per batch item once all `nblk` per-block
+// per-group partial sums (double, [nblk, G, 2]) of that item are visible.  Thread (sub, g) adds blocks sub, sub + nsub, ... of group g, a fixed-shape LDS
+// tree adds the nsub subsets (deterministic: the order depends on nblk and G only), thread g turns the totals into mean / rstd (double
+// E[x^2] - E[x]^2 of sums that are exact to fp32 round-off per block) and every channel gets its folded affine pair.
 constexpr int GN_PT = 1024;     // threads of a partial-sum workgroup
+struct GnFinalArgs { int C, G, V; float eps; const float* gamma; const float* beta; float* stats; float* affine; };
+AE_DEV void groupnorm_finalize_block(const double* __restrict__ part_nb, int nblk, int nb, const GnFinalArgs& f, double (*sh)[2], float* sh_mu, float* sh_rstd) {
+    const int tid = threadIdx.x, G = f.G, nsub = GN_PT / G;
+    const int g = tid % G, sub = tid / G;
+    double ssum = 0.0, qsum = 0.0;
+    for (int b = sub; b < nblk; b += nsub) {
+        const double2 v = *(const double2*)(part_nb + ((size_t)b * G + g) * 2);
+        ssum += v.x; qsum += v.y;
+    }
+    sh[tid][0] = ssum; sh[tid][1] = qsum;
+    __syncthreads();
+    for (int stride = nsub >> 1; stride > 0; stride >>= 1) {
+        if (sub < stride) { sh[tid][0] += sh[tid + stride * G][0]; sh[tid][1] += sh[tid + stride * G][1]; }
+        __syncthreads();
+    }
+    const int cpg = f.C / G;
+    if (tid < G) {
+        const double N = (double)f.V * cpg;
+        const double mu = sh[tid][0] / N;
+        const double var = fmax(sh[tid][1] / N - mu * mu, 0.0);
+        const float rstd = (float)(1.0 / sqrt(var + (double)f.eps));
+        sh_mu[tid] = (float)mu; sh_rstd[tid] = rstd;
+        f.stats[((size_t)nb * G + tid) * 2 + 0] = (float)mu;
+        f.stats[((size_t)nb * G + tid) * 2 + 1] = rstd;
+    }
+    __syncthreads();
+    for (int c = tid; c < f.C; c += GN_PT) {
+        const int gg = c / cpg;
+        const float sc = sh_rstd[gg] * f.gamma[c];
+        f.affine[((size_t)nb * 2 + 0) * f.C + c] = sc;
+        f.affine[((size_t)nb * 2 + 1) * f.C + c] = f.beta[c] - sh_mu[gg] * sc;
+    }
+}
+
+// Streaming read at HBM rate needs many loads in flight: 1024 threads per workgroup, four independent 16-byte loads per thread
+// and iteration (256 workgroups x 1024 x 64 B = 16 MiB outstanding on the whole chip).  Per block: per-channel fp32 (sum, sum of squares) by a
+// fixed-shape LDS tree, folded to per-GROUP doubles part[nb, blk, g, (sum, sumsq)] in channel order.
+// FUSED (round 5): the block that finishes LAST for its batch item (agent-scope fence + ticket counter[nb], which it resets to zero for the next call /
+// graph replay) runs the statistics tail itself: one launch per GroupNorm instead of two (1 320 fewer launches per encode + decode), and the
+// dependent apply launch no longer waits for a 32-workgroup kernel to start and drain.
+template <bool FUSED>
 __global__ __launch_bounds__(GN_PT) void groupnorm_partial_kernel(const unsigned short* __restrict__ x, int V, int C, int vpb,
-                                                                  float* __restrict__ part) {
+                                                                  double* __restrict__ part, GnFinalArgs fa, int* __restrict__ counter) {
     __shared__ float red[GN_PT][17];                 // (sum[8], sumsq[8]) per thread, padded against bank conflicts
+    __shared__ float sh_mu[64], sh_rstd[64];
+    __shared__ int sh_last;
     const int nb = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
     const int oct_per_vox = C >> 3;                  // 16-byte pieces per voxel (divides 256)
     const int tid = threadIdx.x;
@@ -56,53 +101,30 @@ __global__ __launch_bounds__(GN_PT) void groupnorm_partial_kernel(const unsigned
         }
         __syncthreads();
     }
-    if (tid < oct_per_vox) {
-        float* dst = part + (((size_t)nb * nblk + blk) * 2) * C + tid * 8;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { dst[e] = red[tid][e]; dst[C + e] = red[tid][8 + e]; }
+    double* part_nb = part + (size_t)nb * nblk * fa.G * 2;
+    if (tid < fa.G) {                                 // channels of group tid, in channel order, in double
+        const int cpg = C / fa.G;
+        double ds = 0.0, dq = 0.0;
+        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { ds += (double)red[c >> 3][c & 7]; dq += (double)red[c >> 3][8 + (c & 7)]; }
+        *(double2*)(part_nb + ((size_t)blk * fa.G + tid) * 2) = make_double2(ds, dq);
+        if (FUSED) __threadfence();                   // release (the writing wave only): this block's partial row before its ticket
     }
+    if (!FUSED) return;
+    __syncthreads();
+    if (tid == 0) sh_last = (atomicAdd(&counter[nb], 1) == nblk - 1);
+    __syncthreads();
+    if (!sh_last) return;
+    __threadfence();                                  // acquire: every other block's row
+    groupnorm_finalize_block(part_nb, nblk, nb, fa, reinterpret_cast<double(*)[2]>(&red[0][0]), sh_mu, sh_rstd);
+    if (tid == 0) counter[nb] = 0;                    // ready for the next launch on this counter (stream order / graph replay)
 }
 
-// One workgroup per (group, batch item): thread b adds the group's channels of partial block b, b+256, ... in double, a fixed-
-// shape LDS tree adds the threads (deterministic), thread 0 turns the totals into mean / rstd (the partials are fp32 sums, so
-// a double E[x^2]-E[x]^2 is as exact as any merge order of them) and the group's channels get their folded affine pair.
-// (One workgroup per batch item walked all G x nblk partial rows through a single CU's texture path: 15-28 us; this spreads
-// them over G CUs.)
-__global__ __launch_bounds__(256) void groupnorm_finalize_kernel(const float* __restrict__ part, int nblk, int C, int G, int V,
-                                                                 float eps, const float* __restrict__ gamma,
-                                                                 const float* __restrict__ beta, float* __restrict__ stats,
-                                                                 float* __restrict__ affine) {
-    __shared__ double sh_s[256], sh_q[256];
-    __shared__ float sh_mu, sh_rstd;
-    const int g = blockIdx.x, nb = blockIdx.y, tid = threadIdx.x;
-    const int cpg = C / G;
-    double ssum = 0.0, qsum = 0.0;
-    for (int b = tid; b < nblk; b += 256) {
-        const float* ps = part + (((size_t)nb * nblk + b) * 2) * C + g * cpg;
-        for (int c = 0; c < cpg; ++c) { ssum += (double)ps[c]; qsum += (double)ps[C + c]; }
-    }
-    sh_s[tid] = ssum; sh_q[tid] = qsum;
-    __syncthreads();
-    for (int stride = 128; stride > 0; stride >>= 1) {
-        if (tid < stride) { sh_s[tid] += sh_s[tid + stride]; sh_q[tid] += sh_q[tid + stride]; }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        const double N = (double)V * cpg;
-        const double mu = sh_s[0] / N;
-        const double var = fmax(sh_q[0] / N - mu * mu, 0.0);
-        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-        sh_mu = (float)mu; sh_rstd = rstd;
-        stats[((size_t)nb * G + g) * 2 + 0] = (float)mu;
-        stats[((size_t)nb * G + g) * 2 + 1] = rstd;
-    }
-    __syncthreads();
-    for (int i = tid; i < cpg; i += 256) {
-        const int c = g * cpg + i;
-        const float sc = sh_rstd * gamma[c];
-        affine[((size_t)nb * 2 + 0) * C + c] = sc;
-        affine[((size_t)nb * 2 + 1) * C + c] = beta[c] - sh_mu * sc;
-    }
+// The two-launch form (counter == NULL): the same tail as its own kernel, one workgroup per batch item -> bit-identical to the fused form.
+__global__ __launch_bounds__(GN_PT) void groupnorm_finalize_kernel(const double* __restrict__ part, int nblk, GnFinalArgs fa) {
+    __shared__ double sh[GN_PT][2];
+    __shared__ float sh_mu[64], sh_rstd[64];
+    const int nb = blockIdx.x;
+    groupnorm_finalize_block(part + (size_t)nb * nblk * fa.G * 2, nblk, nb, fa, sh, sh_mu, sh_rstd);
 }
 
 // cond[nb, zv, 0, c] = by[c] + sum_j wy[c,j] zq[nb,zv,j];   cond[nb, zv, 1, c] = bb[c] + sum_j wb[c,j] zq[nb,zv,j]
@@ -266,18 +288,24 @@ using namespace aether;
 #define AE_STREAM ((hipStream_t)stream)
 
 extern "C" int aether_groupnorm_stats(const void* x, int NB, int V, int C, int G, float eps, const float* gamma, const float* beta,
-                                      float* partial_ws, int nblk, float* stats, float* affine, void* stream) {
+                                      float* partial_ws, int nblk, float* stats, float* affine, int* counter, void* stream) {
     if (!x || !partial_ws || !stats || !affine || !gamma || !beta) return aether_set_error(AETHER_ERR_ARG, "groupnorm_stats: null pointer");
-    if (C % 8 != 0 || C > 2048 || 256 % (C / 8) != 0 || C % G != 0 || G > 64 || 256 % G != 0)
+    if (C % 8 != 0 || C > 2048 || 256 % (C / 8) != 0 || C % G != 0 || G > 64 || 256 % G != 0 || C < 2 * G)
         return aether_set_error(AETHER_ERR_SHAPE, "groupnorm_stats: unsupported C/G");
     if (nblk <= 0 || NB <= 0 || V <= 0) return aether_set_error(AETHER_ERR_ARG, "groupnorm_stats: bad sizes");
+    if (((uintptr_t)partial_ws & 15) || ((uintptr_t)counter & 3)) return aether_set_error(AETHER_ERR_ALIGN, "groupnorm_stats: partial_ws must be 16-byte aligned");
     const int vpb = (V + nblk - 1) / nblk;
     const int nblk_eff = (V + vpb - 1) / vpb;
-    hipLaunchKernelGGL(groupnorm_partial_kernel, dim3(nblk_eff, NB), dim3(GN_PT), 0, AE_STREAM, (const unsigned short*)x, V, C, vpb, partial_ws);
+    GnFinalArgs fa = {C, G, V, eps, gamma, beta, stats, affine};
+    double* part = reinterpret_cast<double*>(partial_ws);           // [NB, nblk_eff, G, 2] doubles: 16 G <= 8 C bytes per block
+    if (counter != nullptr) {
+        hipLaunchKernelGGL(groupnorm_partial_kernel<true>, dim3(nblk_eff, NB), dim3(GN_PT), 0, AE_STREAM, (const unsigned short*)x, V, C, vpb, part, fa, counter);
+        return aether_check_launch("groupnorm_stats (fused)");
+    }
+    hipLaunchKernelGGL(groupnorm_partial_kernel<false>, dim3(nblk_eff, NB), dim3(GN_PT), 0, AE_STREAM, (const unsigned short*)x, V, C, vpb, part, fa, nullptr);
     int rc = aether_check_launch("groupnorm_partial");
     if (rc) return rc;
-    hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(G, NB), dim3(256), 0, AE_STREAM, partial_ws, nblk_eff, C, G, V, eps, gamma, beta,
-                       stats, affine);
+    hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(NB), dim3(GN_PT), 0, AE_STREAM, part, nblk_eff, fa);
     return aether_check_launch("groupnorm_finalize");
 }
 

@@ -12,8 +12,17 @@ from aether_amd.vae import AetherVAE  # noqa: E402
 
 
 def main():
+    import argparse
+    from aether_amd import _lib
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", choices=["encode", "decode"], default=None, help="time one direction only (per-direction rocprofv3 traces)")
+    ap.add_argument("--lanes", type=int, default=2, choices=[1, 2], help="1 = no AETHER_VAE_TWO_LANES: kernels of one call do not overlap, so a kernel trace attributes time per kernel")
+    ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--out", default="gpurun_out/vae_bench.json")
+    args = ap.parse_args()
     dev = torch.device("cuda:0")
-    vae = AetherVAE(device=dev).init_random_weights(0)
+    flags = _lib.AETHER_GEMM_WIDE_STORE | (_lib.AETHER_VAE_TWO_LANES if args.lanes == 2 else 0)
+    vae = AetherVAE(device=dev, flags=flags).init_random_weights(0)
     vae.enable_tiling(); vae.enable_slicing()
     g = torch.Generator(device=dev).manual_seed(0)
     yy, xx = torch.meshgrid(torch.arange(480, device=dev).float(), torch.arange(720, device=dev).float(), indexing="ij")
@@ -22,24 +31,26 @@ def main():
     res = {}
     for name, fn, flop in (("encode_41x480x720", lambda: vae.encode(video).latent_dist.parameters, 175e12),
                            ("decode_11x60x90", None, 369e12)):
+        if args.only and not name.startswith(args.only):
+            continue
         if fn is None:
             z = (torch.randn(1, 16, 11, 60, 90, generator=g, device=dev)).to(torch.bfloat16)
             fn = lambda: vae.decode(z).sample  # noqa: E731
         out = fn()
         torch.cuda.synchronize()
         times = []
-        for _ in range(2):
+        for _ in range(args.reps):
             t0 = time.perf_counter()
             out = fn()
             torch.cuda.synchronize()
             times.append(time.perf_counter() - t0)
         t = min(times)
-        res[name] = {"seconds": t, "TFLOPs_algorithmic": flop / t / 1e12, "frac_mfma_peak": flop / t / 2.5e15,
+        res[name] = {"lanes": args.lanes, "gn_two_launch": os.environ.get("AETHER_VAE_GN_TWO_LAUNCH", "0"), "seconds": t, "TFLOPs_algorithmic": flop / t / 1e12, "frac_mfma_peak": flop / t / 2.5e15,
                      "out_shape": list(out.shape), "finite": bool(torch.isfinite(out.float()).all()), "out_std": float(out.float().std())}
         print(name, res[name], flush=True)
     res["peak_mem_GB"] = torch.cuda.max_memory_allocated() / 1e9
     os.makedirs("gpurun_out", exist_ok=True)
-    json.dump(res, open("gpurun_out/vae_bench.json", "w"), indent=1)
+    json.dump(res, open(args.out, "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -34,7 +34,8 @@ def get_window_starts(total_frames: int, sliding_window_size: int, temporal_stri
 class WindowResult:
     """One window's outputs.  Contract: `rgb` / `disparity` are numpy float32 arrays, EXCEPT after `run_windows(keep_on_device=True)`
     on a CUDA gather device, where they are float32 torch tensors on that device (views of the gathered buffers, for
-    `blend_and_merge_window_results(..., device=)`); `raymap` is always numpy."""
+    `blend_and_merge_window_results(..., device=)`); `raymap` is numpy (only `run_windows_merged` hands `WindowMerger.add` a device tensor, which
+    the merger fetches asynchronously)."""
     start: int
     rgb: np.ndarray         # [F, H, W, 3] float32 (a torch tensor after run_windows(keep_on_device=True))
     disparity: np.ndarray   # [F, H, W]    float32 (likewise)
@@ -132,7 +133,11 @@ def run_windows_merged(call_window: Callable[[int], "object"], starts: Sequence[
     computes its window of round j + 1.  After the last round only that round's merge, the back-projection and the D2H copy remain (with one
     gather at the very end, as `run_windows` + `blend_and_merge_window_results` do, the whole merge is a serial tail on rank 0).
     Returns (rgb, disparity, poses, pointmaps) on rank 0 and None elsewhere; values are those of `blend_and_merge_window_results(run_windows(...),
-    device=...)` bit for bit (same kernels, same order).  `timings` (a dict) receives 'windows_and_gather' and 'merge_tail' in seconds."""
+    device=...)` bit for bit (same kernels, same order).  `timings` (a dict) receives 'windows_and_gather' and 'merge_tail' in seconds.
+    Rank 0 never waits on the host for a merge: the per-pixel passes are enqueued on the side stream, each window's raymap comes to the host by a
+    non-blocking copy and its camera algebra runs one round late (WindowMerger.add / _drain).
+    `pinned=True`: the returned arrays are views of process-wide page-locked buffers — valid until the next merge of the same shape
+    (`release_pinned_buffers()` frees them); copy them if they must live longer."""
     import time
     dist = _dist()
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
@@ -155,7 +160,7 @@ def run_windows_merged(call_window: Callable[[int], "object"], starts: Sequence[
         if merger is None:
             merger = WindowMerger(total_frames=starts[-1] + rgb.shape[0], window_frames=rgb.shape[0], frame_hw=tuple(disp.shape[1:]), height=height, width=width,
                                   device=dev, smooth_camera=smooth_camera, smooth_method=smooth_method, out_dtype=out_dtype, pinned=pinned)
-        merger.add(WindowResult(starts[idx], rgb, disp, ray.cpu().numpy().copy()))
+        merger.add(WindowResult(starts[idx], rgb, disp, ray if ray.device.type == "cuda" else ray.cpu().numpy().copy()))
 
     for j in range(n_rounds):
         idx = j * world + rank
@@ -311,6 +316,13 @@ def blend_and_merge_window_results(results: Sequence[WindowResult], *, height: i
 _PINNED: dict = {}
 
 
+def release_pinned_buffers() -> None:
+    """Free the page-locked result buffers of `pinned=True` merges (1.9 GB for a 192-frame float32 clip, 3.7 GB in float64).  Arrays returned by
+    earlier `pinned=True` merges are VIEWS of these buffers: they are overwritten by the next merge of the same shape and must not be used after
+    this call — copy what has to outlive either."""
+    _PINNED.clear()
+
+
 def _pinned(tag: str, shape, dtype) -> torch.Tensor:
     """Page-locked host buffers for the merged arrays, allocated once per (shape, dtype) and reused by later merges: a D2H copy into pageable
     memory runs at ~7 GB/s on this box (0.5 s for the 3.7 GB a 192-frame clip's float64 arrays), into pinned memory at PCIe speed."""
@@ -352,6 +364,9 @@ class WindowMerger:
         self.poses = np.empty((self.total, 4, 4))
         self.focals = np.empty((self.total,))
         self.end, self.prev_start, self.count = 0, None, 0
+        # camera algebra of the windows whose raymap is still on its way to the host: (raymap pinned buffer | array, event | None, t0, ov, first)
+        self._pending: list = []
+        self._free_ray: list = []
 
     def _up(self, a):
         return (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))).to(self.device)
@@ -369,20 +384,22 @@ class WindowMerger:
                         "aether_merge_window")
 
     def add(self, r: "WindowResult") -> None:
-        from . import geometry as G
+        """Merge the next window.  The per-pixel passes are enqueued on the current stream without any host synchronisation; the camera algebra
+        (a few dozen 4x4 matrices, host numpy like the reference's) needs the window's raymap on the host: a device raymap is fetched by a
+        non-blocking copy into page-locked memory + an event, and the algebra of a window runs when that event has fired — at a later `add` or in
+        `finish` — so the caller can enqueue its next window before this one's merge has executed (`run_windows_merged`).  Order of the host
+        arithmetic, hence every value, is that of the immediate form."""
         H, W, n_win, device = self.H, self.W, self.n_win, self.device
-        rgb, disp, poses, focals = self.rgb, self.disp, self.poses, self.focals
+        rgb, disp = self.rgb, self.disp
         if self.count == 0:
             assert r.start == 0
             if self.native:
                 self._write_window(self._up32(r.rgb), self._up32(r.disparity), 0, 0, [], None)
             else:
                 rgb[:n_win], disp[:n_win] = self._up(r.rgb), self._up(r.disparity)
-            pm0 = G.postprocess_pointmap(_host(r.disparity), r.raymap, vae_downsample_scale=8, ray_o_scale_inv=0.1,
-                                         smooth_camera=self.smooth_camera, smooth_method=self.sm, with_pointmap=False)
-            poses[:n_win] = pm0["camera_pose"]
-            focals[:n_win] = (pm0["intrinsics"][:, 0, 0] + pm0["intrinsics"][:, 1, 1]) / 2
+            self._queue_cameras(r.raymap, 0, 0, True)
             self.end, self.prev_start, self.count = n_win, 0, 1
+            self._drain(block=False)
             return
         t0, end = r.start, self.end
         t1 = t0 + r.rgb.shape[0]
@@ -411,8 +428,53 @@ class WindowMerger:
             disp[end:t1] = w_disp[ov:]
             rgb[t0:end] = rgb[t0:end] * fade[:, None, None, None] + r_rgb[:ov] * (1 - fade[:, None, None, None])
             rgb[end:t1] = r_rgb[ov:]
-        # cameras and focal lengths: a few dozen 4x4 matrices — host
-        w_poses, fov_x, fov_y = G.raymap_to_poses(r.raymap, ray_o_scale_inv=0.1)
+        self._queue_cameras(r.raymap, t0, ov, False)
+        self.end, self.prev_start, self.count = t1, t0, self.count + 1
+        self._drain(block=False)
+
+    def _queue_cameras(self, raymap, t0: int, ov: int, first: bool) -> None:
+        if isinstance(raymap, torch.Tensor) and raymap.device.type == "cuda":
+            buf = self._free_ray.pop() if (self._free_ray and self._free_ray[-1].shape == raymap.shape) else torch.empty(raymap.shape, dtype=torch.float32, pin_memory=True)
+            buf.copy_(raymap, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(raymap.device))
+            self._pending.append((buf, ev, t0, ov, first))
+        else:
+            self._pending.append((_host(raymap), None, t0, ov, first))
+
+    def _drain(self, block: bool) -> None:
+        """Camera algebra of the queued windows, in window order, for every window whose raymap has arrived (all of them when `block`)."""
+        while self._pending:
+            buf, ev, t0, ov, first = self._pending[0]
+            if ev is not None:
+                if block:
+                    ev.synchronize()
+                elif not ev.query():
+                    return
+            self._pending.pop(0)
+            if ev is not None:
+                ray = buf.numpy().copy()                     # raymap_to_poses decodes in place: work on a copy, recycle the pinned buffer
+                self._free_ray.append(buf)
+            else:
+                ray = buf
+            self._cameras(ray, t0, ov, first)
+
+    def _cameras(self, raymap: np.ndarray, t0: int, ov: int, first: bool) -> None:
+        """Cameras and focal lengths of one window (D:292-401 without the per-pixel part): host numpy, float64 like the reference."""
+        from . import geometry as G
+        H, W, n_win = self.H, self.W, self.n_win
+        poses, focals = self.poses, self.focals
+        if first:
+            # with_pointmap=False reads only the raymap (U:283-351): no disparity crosses to the host
+            pm0 = G.postprocess_pointmap(None, raymap, vae_downsample_scale=8, ray_o_scale_inv=0.1,
+                                         smooth_camera=self.smooth_camera, smooth_method=self.sm, with_pointmap=False)
+            poses[:n_win] = pm0["camera_pose"]
+            focals[:n_win] = (pm0["intrinsics"][:, 0, 0] + pm0["intrinsics"][:, 1, 1]) / 2
+            return
+        end = t0 + ov
+        fade_h = np.linspace(1, 0, ov)
+        w_poses, fov_x, fov_y = G.raymap_to_poses(raymap, ray_o_scale_inv=0.1)
+        t1 = t0 + w_poses.shape[0]
         aR, aT, aS = G.align_camera_extrinsics(w_poses[:ov], poses[t0:end])
         w_aligned = G.apply_transformation(w_poses, aR, aT, aS)
         for i in range(ov):
@@ -422,12 +484,12 @@ class WindowMerger:
         w_focals = (focals[t0:end] / w_focals[:ov]).mean() * w_focals
         focals[t0:end] = focals[t0:end] * fade_h + w_focals[:ov] * (1 - fade_h)
         focals[end:t1] = w_focals[ov:]
-        self.end, self.prev_start, self.count = t1, t0, self.count + 1
 
     def finish(self):
         """Back-projection (U:393-403): world = pose[:3,:4] · [K⁻¹ · (u+.5, v+.5, 1) · depth ; 1], pixel grid in float32 like the reference; then
         the D2H copies (rgb and disparity leave on a copy stream while the back-projection kernel runs)."""
         assert self.end == self.total, "windows missing"
+        self._drain(block=True)
         device, total, H, W = self.device, self.total, self.H, self.W
         K = np.zeros((total, 3, 3))
         K[:, 0, 0] = K[:, 1, 1] = self.focals

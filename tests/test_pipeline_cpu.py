@@ -157,6 +157,12 @@ if world == 1 or dist.get_rank() == 0:
     r = pipe(task="reconstruction", video=T._video(), height=T.H, width=T.W, num_frames=T.F, num_inference_steps=2,
              generator=torch.Generator().manual_seed(5))
     out["rec_rgb"] = r.rgb
+# decode-parallel: BOTH ranks make the reconstruction call; rank 0 decodes rgb, rank 1 disparity, one all-gather
+if world > 1:
+    pipe.disable_cfg_parallel(); pipe.enable_decode_parallel()
+r = pipe(task="reconstruction", video=T._video(), height=T.H, width=T.W, num_frames=T.F, num_inference_steps=2,
+         generator=torch.Generator().manual_seed(5))
+out["dec_rgb"], out["dec_disparity"], out["dec_raymap"] = r.rgb, r.disparity, r.raymap
 np.savez(%(out)r + (".%%d" %% (dist.get_rank() if world > 1 else 0)), **out)
 if world > 1:
     dist.barrier(); dist.destroy_process_group()
@@ -188,3 +194,6 @@ def test_cfg_parallel_two_ranks_gloo(tmp_path):
         a, b = single[k].astype(np.float64), r0[k].astype(np.float64)
         assert a.shape == b.shape and np.abs(a - b).max() <= 2e-2 * max(1.0, np.abs(a).max()), (k, np.abs(a - b).max())
     assert np.array_equal(single["rec_rgb"], r0["rec_rgb"])
+    # decode-parallel reconstruction: the same kernels on the same (replicated) latents -> bit-identical to one rank, on both ranks
+    for k in ("dec_rgb", "dec_disparity", "dec_raymap"):
+        assert np.array_equal(single[k], r0[k]) and np.array_equal(single[k], r1[k]), k

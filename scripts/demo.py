@@ -236,6 +236,16 @@ def main(argv=None) -> None:
 
         # window outputs never leave HBM between the pipeline, the gather to rank 0 (RCCL) and the device merge
         pipeline.keep_outputs_on_device = not args.align_pointmaps
+        if len(starts) == 1 and world >= 2:
+            # ONE window on several GPUs: the two final decodes (40 % of a 4-step clip) go to ranks 0 and 1 (AetherV1PipelineCogVideoX.
+            # enable_decode_parallel: replicated encode + loop, one all-gather of the decoded videos; bit-identical to one rank).  Rank 1 makes
+            # the same call as rank 0's call inside the window driver below and drops the result.
+            import torch.distributed as dist
+            pair = dist.new_group([0, 1])                 # collective over all ranks
+            if rank < 2:
+                pipeline.enable_decode_parallel(pair)
+            if rank == 1:
+                call_window(starts[0])
         if args.align_pointmaps:
             # the reference's point-map alignment branch stays on the host (numpy): gather everything, then merge
             results = run_windows(call_window, starts, gather_device=device, keep_on_device=False)

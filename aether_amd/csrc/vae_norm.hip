@@ -9,6 +9,7 @@
 //                                 resolution pass only gathers 2 x 8 floats per 16-byte piece
 //   4. groupnorm_apply_kernel     one streaming read of x + one write into the next convolution's zero-bordered
 //                                 input volume:  silu( (x*scale+shift) [* Y(zq) + B(zq)] )
+#include <stdlib.h>
 #include "common.hpp"
 #include "../../include/aether_hip.h"
 
@@ -182,10 +183,12 @@ struct GnApplyArgs {
 // tid + 256k does not depend on k: its affine pair lives in registers) and walks runs of RW consecutive voxels that share one
 // latent voxel: the SpatialNorm3D pair (4 x 16 B of fp32) is fetched once per run instead of once per voxel, and the RW
 // 16-byte loads of a run are all in flight before the first is used.  RW = min(8, W / zW) with conditioning, else the largest
-// of 8, 4, 2, 1 that divides W.
+// of 8, 4, 2, 1 that divides W.  Threads per workgroup (round 5): the smallest multiple of the octets per voxel that covers the row's units in
+// ceil(units / 256) equal passes — 240 for the 360-voxel, 128-channel rows (three full passes instead of 256 + 256 + 208), 144 for the 144-voxel edge
+// tiles (two passes instead of 256 + 32) — instead of always 256.
 template <int RW>
 __global__ __launch_bounds__(256) void groupnorm_apply_kernel(GnApplyArgs p) {
-    const int nb = blockIdx.y;
+    const int nb = blockIdx.y, bd = blockDim.x;      // bd: a multiple of the octets per voxel, chosen by the host so that the passes over a row are balanced
     const int t = blockIdx.x / p.H, h = blockIdx.x - t * p.H;
     const int opv = 1 << p.log2_opv;
     const int units = (p.W / RW) << p.log2_opv;
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(GnApplyArgs p) {
     const f32x4 h0 = *(const f32x4*)(aff + p.C), h1 = *(const f32x4*)(aff + p.C + 4);
     const float* crow = nullptr;
     if (p.cond != nullptr) crow = p.cond + ((((size_t)nb * p.zT + p.tmap[t]) * p.zH + h / p.rh) * p.zW) * 2 * p.C + c0;
-    for (int u = threadIdx.x; u < units; u += 256) {
+    for (int u = threadIdx.x; u < units; u += bd) {
         const int wb = u >> p.log2_opv;
         const size_t off = (size_t)(wb * RW) * p.C + c0;
         u16x8 raw[RW];
@@ -253,21 +256,21 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(GnApplyArgs p) {
         const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
         for (int fi = 0; fi < nfr; ++fi) {
             unsigned short* row0 = yrow - (size_t)p.pw * p.C - (size_t)fi * plane;      // start of this padded row in frame t + pt - fi
-            for (int u = threadIdx.x; u < (p.pw + right) * vec_per_vox; u += 256) {
+            for (int u = threadIdx.x; u < (p.pw + right) * vec_per_vox; u += bd) {
                 const int vx = u >> p.log2_opv, o8 = (u & (opv - 1)) << 3;
                 const int col = vx < p.pw ? vx : p.pw + p.W + (vx - p.pw);
                 *(uint4*)(row0 + (size_t)col * p.C + o8) = zero;
             }
             if (h == 0)
-                for (int u = threadIdx.x; u < p.ph * p.oW * vec_per_vox; u += 256) *(uint4*)(row0 - (size_t)p.ph * prow + (size_t)u * 8) = zero;
+                for (int u = threadIdx.x; u < p.ph * p.oW * vec_per_vox; u += bd) *(uint4*)(row0 - (size_t)p.ph * prow + (size_t)u * 8) = zero;
             if (h == p.H - 1)
-                for (int u = threadIdx.x; u < below * p.oW * vec_per_vox; u += 256) *(uint4*)(row0 + prow + (size_t)u * 8) = zero;
+                for (int u = threadIdx.x; u < below * p.oW * vec_per_vox; u += bd) *(uint4*)(row0 + prow + (size_t)u * 8) = zero;
         }
     }
     if (p.causal && t == 0 && p.front_prev != nullptr) {             // later chunks: front frames = the saved pair, row by row
         const unsigned short* prow = p.front_prev + (size_t)nb * 2 * plane + row_in_plane;
         const int vecs = p.W << p.log2_opv;
-        for (int u = threadIdx.x; u < vecs; u += 256) {
+        for (int u = threadIdx.x; u < vecs; u += bd) {
             const uint4 a = *(const uint4*)(prow + (size_t)u * 8), b = *(const uint4*)(prow + plane + (size_t)u * 8);
             *(uint4*)(yrow - 2 * plane + (size_t)u * 8) = a;
             *(uint4*)(yrow - plane + (size_t)u * 8) = b;
@@ -348,7 +351,12 @@ static int groupnorm_apply_impl(const void* x, int NB, int T, int H, int W, int 
     } else {
         rw = (W % 8 == 0) ? 8 : (W % 4 == 0) ? 4 : (W % 2 == 0) ? 2 : 1;
     }
-    const dim3 grid(T * H, NB), block(256);
+    const int units = (W / rw) << l2, opv = 1 << l2;
+    const int npass = (units + 255) / 256;
+    int bd = ((units + npass - 1) / npass + opv - 1) / opv * opv;
+    static const bool fixed256 = [] { const char* e = getenv("AETHER_GN_APPLY_FIXED_BLOCK"); return e && e[0] == '1'; }();     // A/B switch
+    if (fixed256 || bd > 256 || bd < 64) bd = 256;
+    const dim3 grid(T * H, NB), block(bd);
     switch (rw) {
         case 8: hipLaunchKernelGGL(groupnorm_apply_kernel<8>, grid, block, 0, AE_STREAM, p); break;
         case 4: hipLaunchKernelGGL(groupnorm_apply_kernel<4>, grid, block, 0, AE_STREAM, p); break;

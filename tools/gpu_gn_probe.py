@@ -61,8 +61,9 @@ def main():
         vol = vae._norm_to_padded(x, norm, 2, 1, True, zq, 1e-6)
         timed("causal_front", lambda: vae._causal_front(vol, cache, "k"))
         nbytes = x.numel() * 2
-        prof["stats_GBps"] = nbytes / prof["stats(partial+finalize)"] / 1e3
-        apply_us = prof["norm_to_padded(stats+cond+apply)"] - prof["stats(partial+finalize)"]
+        prof["stats_GBps"] = nbytes / prof["stats(one launch, last block merges)"] / 1e3
+        prof["stats_two_launch_GBps"] = nbytes / prof["stats(partial+finalize, two launches)"] / 1e3
+        apply_us = prof["norm_to_padded(stats+cond+apply)"] - prof["stats(one launch, last block merges)"]
         prof["apply+cond_us"] = apply_us
         prof["apply_GBps"] = 2 * nbytes / apply_us / 1e3
         out.append(dict(shape=shp, MB=nbytes / 1e6, **{k: round(v, 1) for k, v in prof.items()}))

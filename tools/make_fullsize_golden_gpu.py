@@ -122,28 +122,29 @@ def stage_pin(dit):
 
 
 class _HostVAE:
-    """The VAE stays on the host CPU (single-frame encodes: seconds).  Decodes are done later, in the build container, from the stored latents."""
-    def __init__(self, vae):
-        self.vae, self.config = vae, vae.config
+    """The VAE stays on the host CPU (single-frame encodes: seconds).  Decodes are done later, in the build container, from the stored latents.
+    dtype = bfloat16: the encoder runs in the reference dtype (bf16 weights — exact, they are bf16-representable — and bf16 activations)."""
+    def __init__(self, vae, dtype=torch.float32):
+        self.vae, self.config, self.dtype = (vae if dtype == torch.float32 else vae.to(dtype)), vae.config, dtype
 
     def encode(self, x):
-        return self.vae.encode(x)
+        return self.vae.encode(x.to(self.dtype))
 
     def decode(self, z):
         import types
         return types.SimpleNamespace(sample=torch.zeros(z.shape[0], 3, (z.shape[2] - 1) * 4 + 1, z.shape[3] * 8, z.shape[4] * 8, dtype=z.dtype))
 
 
-_VAE = []
+_VAE = {}
 
 
-def host_vae():
-    if not _VAE:
-        _VAE.append(_HostVAE(fc.build_oracle_vae()))
-    return _VAE[0]
+def host_vae(dtype=torch.float32):
+    if dtype not in _VAE:
+        _VAE[dtype] = _HostVAE(fc.build_oracle_vae(), dtype)
+    return _VAE[dtype]
 
 
-def run_guided(dit, task, steps, keep, compute_dtype):
+def run_guided(dit, task, steps, keep, compute_dtype, vae_dtype=torch.float32):
     from aether_amd.scheduler import CogVideoXDPMScheduler
     from oracle.pipeline import sample
     case = fc.GUIDED_CASES[task]
@@ -177,7 +178,7 @@ def run_guided(dit, task, steps, keep, compute_dtype):
             return (dit(hidden_states=hidden_states.to(torch.bfloat16), encoder_hidden_states=encoder_hidden_states.to(torch.bfloat16), timestep=timestep, **kw)[0],)
 
     t0 = time.perf_counter()
-    sample(task, dit if compute_dtype == torch.float32 else AsBf16(), host_vae(), CogVideoXDPMScheduler(), fc.prompt_embeds(), image=image, goal=goal,
+    sample(task, dit if compute_dtype == torch.float32 else AsBf16(), host_vae(vae_dtype), CogVideoXDPMScheduler(), fc.prompt_embeds(), image=image, goal=goal,
            raymap=raymap, height=fc.HEIGHT, width=fc.WIDTH, num_frames=fc.FRAMES, num_inference_steps=steps,
            generator=torch.Generator().manual_seed(fc.GUIDED_SEED), rope=_rope(), compute_dtype=torch.float32, trace=trace, device=DEV, vae_device="cpu")
     trace.update(step_lat=step_lat, step_seconds=times, noise_pred_rms=rms, noise_pred_max=mx, seconds_total=time.perf_counter() - t0)
@@ -227,6 +228,30 @@ def stage_calib(dit32, runs):
                                "trajectories on the named inputs, dynamic CFG, identical noise and condition latents", **res}, f, indent=1)
 
 
+def stage_calib_full(dit32, tasks):
+    """The WHOLE guided call in the reference dtype — bf16 VAE encode of the observation (host CPU, torch's bf16 kernels) AND bf16 transformer — against
+    the committed fp32 fixtures (tests/golden/fullsize_<task>50.npz): what `D:218,226` + `P:297` (everything loaded and run as bf16) costs end to end
+    over 50 guided steps.  This is the number the native path's full-call distance is comparable with (its VAE encode is bf16 too)."""
+    dit = dit32 if next(dit32.parameters()).dtype == torch.bfloat16 else dit32.to(torch.bfloat16)
+    res = {}
+    for task in tasks:
+        z = np.load(os.path.join(fc.GOLDEN_DIR, f"fullsize_{task}50.npz"))
+        meta = json.loads(str(z["meta"]))
+        kept, steps = list(meta["kept_steps"]), int(meta["steps"])
+        tr = run_guided(dit, task, steps, set(kept), torch.bfloat16, vae_dtype=torch.bfloat16)
+        per = {int(i): fc.metrics(fc.from_bf16_bits(tr["step_lat"][i]).float(), fc.from_bf16_bits(z["step_latents_s6"][k]).float()) for k, i in enumerate(kept)}
+        fin = fc.metrics(tr["final_latents"].cpu().float(), fc.from_bf16_bits(z["final_latents_bits"]).float())
+        cond = tr["condition_latents"].cpu()
+        res[task] = {"steps": steps, "seconds_device": tr["seconds_total"], "per_step_rel_l2": {k: v["rel_l2"] for k, v in per.items()},
+                     "per_step_linf_rel": {k: v["linf_rel"] for k, v in per.items()}, "final_latents": fin,
+                     "condition_sum_bf16_vae": float(cond.double().sum()), "condition_sum_fp32_vae": meta["condition_sum"]}
+        log(f"calib_full {task}: all-bf16 oracle vs fp32 fixture after {steps} guided steps: {json.dumps(fin)}")
+        np.savez_compressed(os.path.join(OUT, f"bf16_full_oracle_{task}{steps}_final_latents.npz"), final_latents_bits=fc.bf16_bits(tr["final_latents"].cpu()))
+        with open(os.path.join(OUT, "bf16_full_oracle_calibration_guided50.json"), "w") as f:
+            json.dump({"case": "the ORACLE in the reference dtype END TO END (bf16 VAE encode of the observation on the host CPU + bf16 transformer with torch's kernels on "
+                               "MI355X) vs the fp32 fixtures, whole guided trajectories on the named inputs, dynamic CFG, identical noise", **res}, f, indent=1)
+
+
 def main():
     """Stages run in the order given; each long stage is skipped (and says so) when its estimate does not fit into what is left of
     AETHER_ORACLE_BUDGET_S (default 1700 s), so one bounded gpurun lease always ends with whatever was finished on disk."""
@@ -244,6 +269,9 @@ def main():
             stage_pin(dit)
             continue
         if st == "calib":
+            continue
+        if st == "calib_full":                                     # needs the committed fixtures; converts the transformer to bf16 in place: LAST stage
+            stage_calib_full(dit, ["prediction", "planning"])
             continue
         task = "prediction" if st.startswith("prediction") else "planning"
         n = int(st[len(task):])

@@ -309,10 +309,16 @@ class AetherVAE:
             ct = self.config.temporal_compression_ratio
             mirror = ((T - 1) * ct + 1, H * down, W * down) if decode else ((T - 1) // ct + 1, H // down, W // down)
             other = self._lib.aether_vae_workspace_bytes(self._handle, int(not decode), *mirror, int(self.use_tiling)) if min(mirror) > 0 else 0
+            if self._graphs:
+                # the captured graphs hold the old workspace's addresses: they are dropped and re-captured (one eager call + one capture per geometry)
+                import warnings
+                warnings.warn(f"AetherVAE: workspace grows to {max(int(need), int(other)) / 2**30:.1f} GiB; {len(self._graphs)} captured hipGraph(s) dropped", stacklevel=3)
             self._workspace = None
             self._graphs.clear()
             torch.cuda.empty_cache()
-            self._ws_bytes = max(int(need), int(other), 0 if self._ws_bytes is None else self._ws_bytes) + (1 << 20)
+            # each query counts the tap-offset tables (a few hundred bytes per distinct convolution shape) of ITS direction only: the slack covers the
+            # other direction's tables, and those of further geometries of the same size class
+            self._ws_bytes = max(int(need), int(other), 0 if self._ws_bytes is None else self._ws_bytes) + (8 << 20)
             self._workspace = torch.empty(self._ws_bytes, dtype=torch.uint8, device=self.device)
         fn = self._lib.aether_vae_decode if decode else self._lib.aether_vae_encode
         what = "aether_vae_decode" if decode else "aether_vae_encode"

@@ -16,7 +16,6 @@ AETHER_EPI_BIAS_GELU = 1
 AETHER_EPI_BIAS_GATE_RES = 2
 AETHER_GEMM_WIDE_STORE = 1
 AETHER_ATTN_EXACT_MAX = 32    # attention: conservative path only (true-maximum shift from tile 0, a-posteriori check per tile)
-AETHER_VAE_CHUNK_PIPELINE = 512  # VAE plan: consecutive frame chunks of a tile batch on two sub-streams, cache dependencies by events
 AETHER_VAE_TWO_LANES = 256    # VAE plan: tile batches of two on two streams (see include/aether_hip.h)
 AETHER_CONV_TAP_REUSE = 128   # conv: K order is (dt, dh, channel block, dw) -> the tap-reuse kernel may be used
 ATTN_Q_SCALE = 0.125 * 1.4426950408889634   # softmax scale x log2(e): the attention kernel works in the log2 domain

@@ -56,11 +56,6 @@ struct AetherVae {
     // handle's own, forked from / joined to the caller's stream with events (capturable: the side stream joins the caller's capture)
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
-    // ---- chunk pipeline (AETHER_VAE_CHUNK_PIPELINE): consecutive frame chunks of a tile batch alternate between the lane's stream and a twin stream
-    // of the handle; the per-convolution cache dependency between them is an event per (chunk, causal convolution), taken from this pool
-    hipStream_t twin[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_twin_join[4] = {nullptr, nullptr, nullptr, nullptr};
-    std::vector<hipEvent_t> ev_pool;
 };
 
 namespace {
@@ -189,44 +184,7 @@ struct Plan {
     int n_lanes = 1;
     hipStream_t lane_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     float* lane_splitk[4] = {nullptr, nullptr, nullptr, nullptr};
-    // chunk pipeline: chunk k of a tile batch runs on sub-stream k & 1 of its lane (0 = the lane's stream, 1 = its twin), with a split-K scratch and an
-    // arena region of its own; `wait_before_apply` = the event of the same convolution's apply launch in the previous chunk (the producer of this
-    // chunk's causal front frames), waited for right before this chunk's apply launch
-    bool pipeline = false;
-    int sub = 0;
-    hipStream_t twin_stream[4] = {nullptr, nullptr, nullptr, nullptr};
-    float* twin_splitk[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t wait_before_apply = nullptr;
-    size_t ev_next = 0;
-    std::map<std::string, hipEvent_t>* apply_events = nullptr;      // per tile batch: key -> event of the last apply launch of that convolution
-    void set_lane(int l) { lane = l; sub = 0; stream = lane_stream[l]; splitk = lane_splitk[l]; }
-    void set_sub(int s2) { sub = s2; stream = s2 ? twin_stream[lane] : lane_stream[lane]; splitk = s2 ? twin_splitk[lane] : lane_splitk[lane]; }
-    hipEvent_t next_event() {
-        if (ev_next == h->ev_pool.size()) {
-            hipEvent_t e = nullptr;
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { fail(AETHER_ERR_LAUNCH, "vae: could not create an event"); return nullptr; }
-            h->ev_pool.push_back(e);
-        }
-        return h->ev_pool[ev_next++];
-    }
-    // both sub-streams of the current lane wait for everything enqueued so far on the other one
-    bool level_sub_streams() {
-        hipEvent_t a = next_event(), b = next_event();
-        if (a == nullptr || b == nullptr) return false;
-        hipStream_t m = lane_stream[lane], t = twin_stream[lane];
-        // the twin waits for the lane's stream FIRST: under stream capture that is what makes it part of the capture, and only then may the
-        // capturing stream wait for an event recorded on it
-        if (hipEventRecord(b, m) != hipSuccess || hipStreamWaitEvent(t, b, 0) != hipSuccess || hipEventRecord(a, t) != hipSuccess ||
-            hipStreamWaitEvent(m, a, 0) != hipSuccess)
-            return fail(AETHER_ERR_LAUNCH, "vae: chunk pipeline: could not level the sub-streams");
-        return true;
-    }
-    void apply_wait() {                              // called right before a causal apply launch
-        if (wait_before_apply != nullptr) {
-            if (hipStreamWaitEvent(stream, wait_before_apply, 0) != hipSuccess) fail(AETHER_ERR_LAUNCH, "vae: chunk pipeline: wait failed");
-            wait_before_apply = nullptr;
-        }
-    }
+    void set_lane(int l) { lane = l; stream = lane_stream[l]; splitk = lane_splitk[l]; }
     // ticket counters of the fused GroupNorm statistics (aether_groupnorm_stats): 4 ints per GroupNorm call of this run, zeroed once at the start of
     // the run and left zero by every launch; null = two launches per GroupNorm (AETHER_VAE_GN_TWO_LAUNCH=1, the A/B switch)
     int* gn_counters = nullptr;
@@ -328,7 +286,6 @@ struct Plan {
             int tmap[64];
             if (x.T > 64) { fail(AETHER_ERR_SHAPE, "vae: more than 64 frames in one chunk"); return vol; }
             nearest_time_map(x.T, zq->T, tmap);
-            if (front_next) apply_wait();
             if (front_next)
                 ok(aether_groupnorm_apply_causal(x.p, x.NB, x.T, x.H, x.W, x.C, affine, 1, vol, x.H + 2 * pad_hw, x.W + 2 * pad_hw, pad_hw, pad_hw, cond,
                                                  zq->T, zq->H, zq->W, tmap, front_prev, front_next, stream), "aether_groupnorm_apply_causal");
@@ -336,7 +293,6 @@ struct Plan {
                 ok(aether_groupnorm_apply(x.p, x.NB, x.T, x.H, x.W, x.C, affine, 1, vol, x.T + pad_t, x.H + 2 * pad_hw, x.W + 2 * pad_hw, pad_t, pad_hw,
                                           pad_hw, cond, zq->T, zq->H, zq->W, tmap, stream), "aether_groupnorm_apply");
         } else if (front_next) {
-            apply_wait();
             ok(aether_groupnorm_apply_causal(x.p, x.NB, x.T, x.H, x.W, x.C, affine, 1, vol, x.H + 2 * pad_hw, x.W + 2 * pad_hw, pad_hw, pad_hw, nullptr, 0,
                                              0, 0, nullptr, front_prev, front_next, stream), "aether_groupnorm_apply_causal");
         } else {
@@ -387,21 +343,7 @@ struct Plan {
         else causal_buffers(key, &prev, &next);
         if (dst == nullptr) dst = alloc((size_t)x.NB * x.T * x.H * x.W * cw.cout_pad * 2);    // the output first: volume + norm scratch sit above it ...
         const size_t mark = top;
-        const bool piped = pipeline && !dry && !reserve_mode && apply_events != nullptr;
-        if (piped) {
-            auto it = apply_events->find(key);
-            wait_before_apply = (it != apply_events->end()) ? it->second : nullptr;      // first chunk: nothing to wait for
-        }
         char* vol = norm_to_padded(x, nw, 2, 1, zq, eps, prev, next);
-        if (piped && !rc) {
-            // the apply launch above wrote this chunk's last two frames into `next`: the same convolution of the NEXT chunk (other sub-stream) may
-            // read them — and overwrite `prev` — once this launch is done
-            hipEvent_t e = next_event();
-            if (e != nullptr) {
-                if (hipEventRecord(e, stream) != hipSuccess) fail(AETHER_ERR_LAUNCH, "vae: chunk pipeline: record failed");
-                (*apply_events)[key] = e;
-            }
-        }
         Act y = conv_gemm(vol, x.NB, x.T + 2, x.H + 2, x.W + 2, x.C, cw, x.T, x.H, x.W, 1, residual, dst);
         top = mark;                                                                          // ... and are released once the convolution is enqueued
         return y;
@@ -609,14 +551,11 @@ struct Plan {
             std::map<std::string, Cache> group_caches;
             caches = &group_caches;
             // reserve the conv caches of this group (sizes from a dry walk of the first chunk's graph)
-            size_t chunk_bytes = 0;                           // arena bytes of one chunk's walk (chunk 0 is the largest: it takes the remainder frames)
             {
                 const bool was_dry = dry; const size_t t0 = top, p0 = peak;
                 dry = true; reserve_mode = true; reserve_list.clear();
-                peak = top;
                 if (decode) decode_chunk(src, sC, sT, sH, sW, crops, NB, ch[0].first, ch[0].second - ch[0].first, g.th, g.tw, true);
                 else encode_chunk(src, sC, sT, sH, sW, crops, NB, ch[0].first, ch[0].second - ch[0].first, g.th, g.tw, true);
-                chunk_bytes = align_up(peak - t0, 256);
                 dry = was_dry; reserve_mode = false; top = t0; peak = std::max(p0, peak);
                 if (rc) return false;
                 for (auto& kv : reserve_list) {
@@ -627,17 +566,8 @@ struct Plan {
             }
             const size_t mark_group = top;
             int t_out = 0;
-            // chunk pipeline: chunk k on sub-stream k & 1 with the arena region k & 1; the only data that crosses from chunk k to chunk k + 1 are the
-            // causal caches, ordered by one event per convolution (causal_conv).  A tile batch starts with both sub-streams level with each other
-            // (the previous batch of this lane used the same arena) and ends the same way.
-            const bool pipe = pipeline && ch.size() > 1;
-            std::map<std::string, hipEvent_t> group_events;
-            apply_events = pipe ? &group_events : nullptr;
-            if (pipe && !dry && !level_sub_streams()) return false;
             for (size_t k = 0; k < ch.size(); ++k) {
-                const int sb = pipe ? (int)(k & 1) : 0;
-                set_sub(sb);
-                top = mark_group + (size_t)sb * chunk_bytes;
+                top = mark_group;
                 const int t0 = ch[k].first, Tc = ch[k].second - ch[k].first;
                 Act y = decode ? decode_chunk(src, sC, sT, sH, sW, crops, NB, t0, Tc, g.th, g.tw, k == 0)
                                : encode_chunk(src, sC, sT, sH, sW, crops, NB, t0, Tc, g.th, g.tw, k == 0);
@@ -655,9 +585,6 @@ struct Plan {
                 t_out += y.T;
             }
             if (t_out != To) return fail(AETHER_ERR_SHAPE, "vae: internal: frame count");
-            apply_events = nullptr;
-            if (pipe && !dry && !level_sub_streams()) return false;
-            set_sub(0);
           }
         }
         set_lane(0);
@@ -686,16 +613,13 @@ struct Plan {
 constexpr size_t kVaeSplitKBytes = (size_t)96 << 20;
 
 int vae_lanes(const AetherVae* h) { return (h->cfg.flags & AETHER_VAE_TWO_LANES) ? 2 : 1; }
-bool vae_pipeline(const AetherVae* h) { return (h->cfg.flags & AETHER_VAE_CHUNK_PIPELINE) != 0; }
 
 int vae_run(AetherVae* h, bool decode, const void* src, int T, int H, int W, int tiling, void* out, void* workspace, size_t workspace_bytes,
             void* stream, size_t* need_out) {
     const int NL = vae_lanes(h);
-    const bool pipe = vae_pipeline(h);
-    const size_t n_splitk = (size_t)NL * (pipe ? 2 : 1);          // one split-K scratch per stream that can run a convolution
-    Plan dry; dry.h = h; dry.stream = nullptr; dry.dry = true; dry.n_lanes = NL; dry.pipeline = pipe;
+    Plan dry; dry.h = h; dry.stream = nullptr; dry.dry = true; dry.n_lanes = NL;
     int oT, oH, oW;
-    dry.alloc(n_splitk * kVaeSplitKBytes);
+    dry.alloc(NL * kVaeSplitKBytes);
     dry.alloc(kGnCounterBytes);
     if (!dry.run(decode, src, T, H, W, tiling, nullptr, &oT, &oH, &oW)) return aether_set_error(dry.rc, dry.err.c_str());
     const size_t pool_total = h->pool_bytes + dry.pool_need;
@@ -703,17 +627,15 @@ int vae_run(AetherVae* h, bool decode, const void* src, int T, int H, int W, int
     if (need_out) { *need_out = need; return AETHER_OK; }
     if (!workspace || ((uintptr_t)workspace & 255)) return aether_set_error(AETHER_ERR_ALIGN, "vae: workspace must be non-null and 256-byte aligned");
     if (workspace_bytes < need) return aether_set_error(AETHER_ERR_ARG, "vae: workspace too small (aether_vae_workspace_bytes)");
-    auto need_taps = dry.dry_taps;                                            // tables this call needs and the workspace does not hold
     if (h->ws != (char*)workspace || h->ws_bytes != workspace_bytes) {        // a new workspace: the tap tables have to be generated in it again
         h->ws = (char*)workspace; h->ws_bytes = workspace_bytes;
         h->pool.clear(); h->taps.clear(); h->pool_bytes = 0;
-        Plan d2; d2.h = h; d2.dry = true; d2.n_lanes = NL; d2.pipeline = pipe; d2.alloc(n_splitk * kVaeSplitKBytes); d2.alloc(kGnCounterBytes);
+        Plan d2; d2.h = h; d2.dry = true; d2.n_lanes = NL; d2.alloc(NL * kVaeSplitKBytes); d2.alloc(kGnCounterBytes);
         if (!d2.run(decode, src, T, H, W, tiling, nullptr, &oT, &oH, &oW)) return aether_set_error(d2.rc, d2.err.c_str());
         if (align_up(d2.pool_need, 256) + d2.peak > workspace_bytes) return aether_set_error(AETHER_ERR_ARG, "vae: workspace too small");
-        need_taps = d2.dry_taps;
     }
     // the table region may grow up to where this call's arena begins; the arena sits at the END of the workspace
-    Plan p; p.h = h; p.stream = (hipStream_t)stream; p.dry = false; p.n_lanes = NL; p.pipeline = pipe;
+    Plan p; p.h = h; p.stream = (hipStream_t)stream; p.dry = false; p.n_lanes = NL;
     p.arena = (char*)workspace + (workspace_bytes - align_up(dry.peak, 256)) / 256 * 256;
     h->pool_cap = (size_t)(p.arena - (char*)workspace);
     p.lane_stream[0] = (hipStream_t)stream;
@@ -731,17 +653,6 @@ int vae_run(AetherVae* h, bool decode, const void* src, int T, int H, int W, int
         p.lane_stream[k] = h->side[k - 1];
     }
     for (int k = 0; k < NL; ++k) p.lane_splitk[k] = (float*)p.alloc(kVaeSplitKBytes);
-    if (pipe)
-        for (int k = 0; k < NL; ++k) {
-            if (h->twin[k] == nullptr) {
-                int lo = 0, hi = 0;
-                hipDeviceGetStreamPriorityRange(&lo, &hi);
-                if (hipStreamCreateWithPriority(&h->twin[k], hipStreamNonBlocking, hi) != hipSuccess)
-                    return aether_set_error(AETHER_ERR_LAUNCH, "vae: could not create a twin stream");
-            }
-            p.twin_stream[k] = h->twin[k];
-            p.twin_splitk[k] = (float*)p.alloc(kVaeSplitKBytes);
-        }
     p.splitk_bytes = kVaeSplitKBytes;
     {
         int* counters = (int*)p.alloc(kGnCounterBytes);
@@ -750,15 +661,6 @@ int vae_run(AetherVae* h, bool decode, const void* src, int T, int H, int W, int
             if (hipMemsetAsync(counters, 0, kGnCounterBytes, (hipStream_t)stream) != hipSuccess) return aether_set_error(AETHER_ERR_LAUNCH, "vae: could not zero the GroupNorm ticket counters");
             p.gn_counters = counters;
         }
-    }
-    // tap-offset tables this call will need and the workspace does not hold yet: generated HERE, on the caller's stream, before any lane / sub-stream
-    // is forked from it (generated lazily on the stream that first needs one, a table could be read by the other sub-stream before it exists)
-    for (auto& kv : need_taps) {
-        int n = 0;
-        p.lane = std::get<0>(kv.first);
-        p.stream = (hipStream_t)stream;
-        p.tap_table(std::get<1>(kv.first), std::get<2>(kv.first), std::get<3>(kv.first), std::get<4>(kv.first), std::get<5>(kv.first), std::get<6>(kv.first), &n);
-        if (p.rc) return aether_set_error(p.rc, p.err.c_str());
     }
     p.set_lane(0);
     if (!p.run(decode, src, T, H, W, tiling, out, &oT, &oH, &oW)) return aether_set_error(p.rc, p.err.c_str());
@@ -769,8 +671,8 @@ int vae_run(AetherVae* h, bool decode, const void* src, int T, int H, int W, int
 
 extern "C" AetherVae* aether_vae_create(const AetherVaeConfig* cfg) {
     if (!cfg) { aether_set_error(AETHER_ERR_ARG, "vae_create: null config"); return nullptr; }
-    if (cfg->flags & ~(AETHER_GEMM_WIDE_STORE | AETHER_VAE_TWO_LANES | AETHER_VAE_CHUNK_PIPELINE)) {      // AETHER_CONV_TAP_REUSE is chosen per convolution by the plan (tap_reuse_max_waste), not by the caller
-        aether_set_error(AETHER_ERR_ARG, "vae_create: undefined flag bits (defined: AETHER_GEMM_WIDE_STORE, AETHER_VAE_TWO_LANES, AETHER_VAE_CHUNK_PIPELINE)");
+    if (cfg->flags & ~(AETHER_GEMM_WIDE_STORE | AETHER_VAE_TWO_LANES)) {      // AETHER_CONV_TAP_REUSE is chosen per convolution by the plan (tap_reuse_max_waste), not by the caller
+        aether_set_error(AETHER_ERR_ARG, "vae_create: undefined flag bits (defined: AETHER_GEMM_WIDE_STORE, AETHER_VAE_TWO_LANES)");
         return nullptr;
     }
     if (cfg->num_levels < 2 || cfg->num_levels > 6 || cfg->latent_channels > 16 || cfg->layers_per_block < 1) {
@@ -789,8 +691,6 @@ extern "C" void aether_vae_destroy(AetherVae* h) {
         if (h->ev_join[k]) hipEventDestroy(h->ev_join[k]);
     }
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
-    for (int k = 0; k < 4; ++k) if (h->twin[k]) hipStreamDestroy(h->twin[k]);
-    for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     delete h;
 }
 

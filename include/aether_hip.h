@@ -254,19 +254,13 @@ typedef struct AetherVaeConfig {
     int sample_height, sample_width; /* 480, 720: tiles are half of it, overlaps 1/6 and 1/5 (diffusers) */
     float norm_eps;                  /* 1e-6 */
     float tap_reuse_max_waste;       /* padded-plane / output-plane ratio up to which the tap-reuse convolution runs (1.06) */
-    int flags;                       /* AETHER_GEMM_* flags forwarded to the GEMMs | AETHER_VAE_TWO_LANES | AETHER_VAE_CHUNK_PIPELINE */
+    int flags;                       /* AETHER_GEMM_* flags forwarded to the GEMMs | AETHER_VAE_TWO_LANES */
 } AetherVaeConfig;
 #define AETHER_VAE_TWO_LANES 256 /* flags bit 8: the batches of equally shaped spatial tiles of one encode / decode (independent of each other until the
                                     cross-fade) are enqueued on TWO streams — the caller's and one owned by the handle (high priority, forked from / joined to
                                     the caller's stream by events; capturable) — assigned by tile area (480x720: the four full tiles | the five edge tiles), so
                                     that the small launches of one lane (512-channel levels at latent resolution, GroupNorm statistics, split-K finalizes)
                                     fill the gaps of the other.  Same kernels, same batches, same arithmetic: bit-identical to the one-lane plan.           */
-#define AETHER_VAE_CHUNK_PIPELINE 512 /* flags bit 9: consecutive FRAME CHUNKS of a tile batch alternate between the lane's stream and a twin stream of the handle.
-                                    Chunk k + 1 needs from chunk k only the causal caches, layer by layer: each causal convolution's GroupNorm-apply launch (which
-                                    writes the chunk's last two frames into the cache) records an event, and the same convolution of the next chunk waits for it right
-                                    before ITS apply launch.  Chunk k + 1 therefore runs one layer behind chunk k — its HBM-bound GroupNorm passes under chunk k's
-                                    MFMA-bound convolution of the same layer and vice versa — for the whole length of the lane, not only while the other lane has
-                                    work left.  Separate arena regions and split-K scratch per sub-stream; same kernels in the same per-chunk order: bit-identical. */
 
 typedef struct AetherVae AetherVae; /* opaque host-side handle: weight table + workspace bookkeeping */
 
@@ -327,7 +321,7 @@ int aether_dit_set_weight(AetherDit* h, const char* name, const void* dev_ptr);
  * table with fewer rows than text + video tokens (no out-of-bounds read).  (NULL, 0) unregisters. */
 int aether_dit_set_pos_embedding(AetherDit* h, const void* table, int rows);
 /* Replace the flags given at creation (e.g. AETHER_ATTN_EXACT_MAX for a measurement).  aether_dit_create / aether_dit_set_flags accept
- * AETHER_GEMM_WIDE_STORE | AETHER_ATTN_EXACT_MAX, aether_vae_create AETHER_GEMM_WIDE_STORE | AETHER_VAE_TWO_LANES | AETHER_VAE_CHUNK_PIPELINE; any other bit is
+ * AETHER_GEMM_WIDE_STORE | AETHER_ATTN_EXACT_MAX, aether_vae_create AETHER_GEMM_WIDE_STORE | AETHER_VAE_TWO_LANES; any other bit is
  * AETHER_ERR_ARG (create: NULL + aether_last_error), so flags of kernel variants that no longer exist are refused, not ignored. */
 int aether_dit_set_flags(AetherDit* h, int flags);
 /* Bytes of scratch the forward needs for batch B and a latent grid F x H x W (latent pixels). */

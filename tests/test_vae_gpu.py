@@ -473,28 +473,3 @@ def test_decode_pair_is_bit_identical(cuda, hip_lib, lanes):
     b2, a2 = vae.decode_pair(zb, za)
     torch.cuda.synchronize()
     assert torch.equal(a2, ref_a) and torch.equal(b2, ref_b)
-
-
-@pytest.mark.parametrize("lanes", [1, 2])
-def test_chunk_pipeline_is_bit_identical(cuda, hip_lib, lanes):
-    """AETHER_VAE_CHUNK_PIPELINE: consecutive frame chunks of a tile batch on two sub-streams, ordered layer by layer through the causal caches by
-    events.  Same kernels in the same per-chunk order as the sequential plan: encode (17 frames = chunks of 9 + 8) and decode (5 latent frames =
-    chunks of 3 + 2) must be bit-identical to it — eagerly, through graph capture, and on replays; tiled (3 x 3 tiles in 4 batches) and untiled."""
-    from aether_amd import _lib
-    from aether_amd.vae import AetherVAE
-    kw = dict(block_out_channels=(64, 128, 128, 128), layers_per_block=1, sample_height=96, sample_width=240)
-    base = _lib.AETHER_GEMM_WIDE_STORE | (_lib.AETHER_VAE_TWO_LANES if lanes == 2 else 0)
-    ref = AetherVAE(kw, device=cuda, flags=base).init_random_weights(3)
-    pip = AetherVAE(kw, device=cuda, flags=base | _lib.AETHER_VAE_CHUNK_PIPELINE).init_random_weights(3)
-    g = torch.Generator(device=cuda).manual_seed(1)
-    video = torch.randn(1, 3, 17, 96, 240, generator=g, device=cuda).to(torch.bfloat16)
-    z = torch.randn(1, 16, 5, 12, 30, generator=g, device=cuda).to(torch.bfloat16)
-    for tiled in (True, False):
-        for v in (ref, pip):
-            (v.enable_tiling if tiled else v.disable_tiling)(); v.enable_slicing()
-        want_e, want_d = ref.encode(video).latent_dist.parameters.clone(), ref.decode(z).sample.clone()
-        for _ in range(4):                                     # eager, capture, replay, replay
-            got_e, got_d = pip.encode(video).latent_dist.parameters, pip.decode(z).sample
-            torch.cuda.synchronize()
-            assert torch.equal(got_e, want_e), f"encode differs (tiled={tiled}, lanes={lanes})"
-            assert torch.equal(got_d, want_d), f"decode differs (tiled={tiled}, lanes={lanes})"

@@ -11,8 +11,6 @@ timeout 200 python tools/gpu_vae_bench.py --out $O/vae_fused.json > $O/vae_fused
 AETHER_VAE_GN_TWO_LAUNCH=1 timeout 200 python tools/gpu_vae_bench.py --out $O/vae_two_launch.json > $O/vae_two_launch.log 2>&1
 AETHER_GN_APPLY_FIXED_BLOCK=1 timeout 200 python tools/gpu_vae_bench.py --out $O/vae_fixed_block.json > $O/vae_fixed_block.log 2>&1
 timeout 200 python tools/gpu_vae_bench.py --lanes 1 --out $O/vae_one_lane.json > $O/vae_one_lane.log 2>&1
-timeout 200 python tools/gpu_vae_bench.py --pipeline --out $O/vae_pipeline.json > $O/vae_pipeline.log 2>&1
-timeout 200 python tools/gpu_vae_bench.py --pipeline --lanes 1 --out $O/vae_pipeline_one_lane.json > $O/vae_pipeline_one_lane.log 2>&1
 grep -h seconds $O/vae_*.log | cut -c1-200
 for d in encode decode; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/vae1_$d/trace -- python tools/gpu_vae_bench.py --lanes 1 --only $d --reps 2 --out $O/vae1_$d.json > $O/vae1_$d.log 2>&1

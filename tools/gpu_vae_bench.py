@@ -17,12 +17,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", choices=["encode", "decode"], default=None, help="time one direction only (per-direction rocprofv3 traces)")
     ap.add_argument("--lanes", type=int, default=2, choices=[1, 2], help="1 = no AETHER_VAE_TWO_LANES: kernels of one call do not overlap, so a kernel trace attributes time per kernel")
-    ap.add_argument("--pipeline", action="store_true", help="AETHER_VAE_CHUNK_PIPELINE: frame chunks of a tile batch on two sub-streams")
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--out", default="gpurun_out/vae_bench.json")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    flags = _lib.AETHER_GEMM_WIDE_STORE | (_lib.AETHER_VAE_TWO_LANES if args.lanes == 2 else 0) | (_lib.AETHER_VAE_CHUNK_PIPELINE if args.pipeline else 0)
+    flags = _lib.AETHER_GEMM_WIDE_STORE | (_lib.AETHER_VAE_TWO_LANES if args.lanes == 2 else 0)
     vae = AetherVAE(device=dev, flags=flags).init_random_weights(0)
     vae.enable_tiling(); vae.enable_slicing()
     g = torch.Generator(device=dev).manual_seed(0)
@@ -46,7 +45,7 @@ def main():
             torch.cuda.synchronize()
             times.append(time.perf_counter() - t0)
         t = min(times)
-        res[name] = {"lanes": args.lanes, "chunk_pipeline": bool(args.pipeline), "gn_two_launch": os.environ.get("AETHER_VAE_GN_TWO_LAUNCH", "0"), "seconds": t, "TFLOPs_algorithmic": flop / t / 1e12, "frac_mfma_peak": flop / t / 2.5e15,
+        res[name] = {"lanes": args.lanes, "gn_two_launch": os.environ.get("AETHER_VAE_GN_TWO_LAUNCH", "0"), "seconds": t, "TFLOPs_algorithmic": flop / t / 1e12, "frac_mfma_peak": flop / t / 2.5e15,
                      "out_shape": list(out.shape), "finite": bool(torch.isfinite(out.float()).all()), "out_std": float(out.float().std())}
         print(name, res[name], flush=True)
     res["peak_mem_GB"] = torch.cuda.max_memory_allocated() / 1e9

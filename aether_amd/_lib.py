@@ -57,7 +57,7 @@ SIGNATURES = {
     "aether_dpm_step": (_i, [_vp, _i, _f, _vp, _fp, _vp, _f, _f, _f, _f, _f, _f, _f, _fp, _fp, _vp, C.c_long, _vp]),
     "aether_conv_gemm_bf16": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _fp, _vp, _i, _fp, _sz, _i, _vp]),
     "aether_im2col_first": (_i, [_vp, C.c_long, C.c_long, C.c_long, C.c_long, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
-    "aether_groupnorm_stats": (_i, [_vp, _i, _i, _i, _i, _f, _fp, _fp, _fp, _i, _fp, _fp, _vp, _vp]),
+    "aether_groupnorm_stats": (_i, [_vp, _i, _i, _i, _i, _f, _fp, _fp, _fp, _i, _fp, _fp, _vp]),
     "aether_spatial_cond": (_i, [_vp, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _fp, _vp]),
     "aether_groupnorm_apply": (_i, [_vp, _i, _i, _i, _i, _i, _fp, _i, _vp, _i, _i, _i, _i, _i, _i, _fp, _i, _i, _i, C.POINTER(C.c_int), _vp]),
     "aether_groupnorm_apply_causal": (_i, [_vp, _i, _i, _i, _i, _i, _fp, _i, _vp, _i, _i, _i, _i, _fp, _i, _i, _i, C.POINTER(C.c_int), _vp, _vp, _vp]),

@@ -1,9 +1,8 @@
 // GroupNorm / SpatialNorm3D of the CogVideoX VAE (diffusers nn.GroupNorm(32, C, eps=1e-6) and CogVideoXSpatialNorm3D,
 // reached from aether/pipelines/aetherv1_pipeline_cogvideox.py:557-618 and P:931,936).  HBM-bound by design:
 //   1. groupnorm_partial_kernel   one streaming read of x [NB, V, C]: per-block, per-group (sum, sum of squares) in double
-//   2. statistics tail            adds the block partials in double (fixed order -> deterministic) and folds gamma/beta into a
-//                                 per-channel affine table y = x*scale[c] + shift[c]; run by the LAST block of launch 1 (ticket
-//                                 counter) or, without a counter, by groupnorm_finalize_kernel
+//   2. groupnorm_finalize_kernel  adds the block partials in double (fixed order -> deterministic) and folds gamma/beta into a
+//                                 per-channel affine table y = x*scale[c] + shift[c]
 //   3. spatial_cond_kernel        SpatialNorm3D only: conv_y / conv_b (1x1x1, 16 -> C) evaluated ONCE at latent
 //                                 resolution; nearest up-sampling commutes with a 1x1x1 convolution, so the full-
 //                                 resolution pass only gathers 2 x 8 floats per 16-byte piece
@@ -15,8 +14,7 @@
 
 namespace aether {
 
-// Statistics tail shared by the fused and the two-launch form: executed by ONE GN_PT-thread workgroup per batch item once all `nblk` per-block
-// per-group partial sums (double, [nblk, G, 2]) of that item are visible.  Thread (sub, g) adds blocks sub, sub + nsub, ... of group g, a fixed-shape LDS
+// Statistics merge: ONE GN_PT-thread workgroup per batch item over the `nblk` per-block per-group partial sums (double, [nblk, G, 2]) of that item.  Thread (sub, g) adds blocks sub, sub + nsub, ... of group g, a fixed-shape LDS
 // tree adds the nsub subsets (deterministic: the order depends on nblk and G only), thread g turns the totals into mean / rstd (double
 // E[x^2] - E[x]^2 of sums that are exact to fp32 round-off per block) and every channel gets its folded affine pair.
 constexpr int GN_PT = 1024;     // threads of a partial-sum workgroup
@@ -57,15 +55,12 @@ AE_DEV void groupnorm_finalize_block(const double* __restrict__ part_nb, int nbl
 // Streaming read at HBM rate needs many loads in flight: 1024 threads per workgroup, four independent 16-byte loads per thread
 // and iteration (256 workgroups x 1024 x 64 B = 16 MiB outstanding on the whole chip).  Per block: per-channel fp32 (sum, sum of squares) by a
 // fixed-shape LDS tree, folded to per-GROUP doubles part[nb, blk, g, (sum, sumsq)] in channel order.
-// FUSED (round 5): the block that finishes LAST for its batch item (agent-scope fence + ticket counter[nb], which it resets to zero for the next call /
-// graph replay) runs the statistics tail itself: one launch per GroupNorm instead of two (1 320 fewer launches per encode + decode), and the
-// dependent apply launch no longer waits for a 32-workgroup kernel to start and drain.
-template <bool FUSED>
-__global__ __launch_bounds__(GN_PT) void groupnorm_partial_kernel(const unsigned short* __restrict__ x, int V, int C, int vpb,
-                                                                  double* __restrict__ part, GnFinalArgs fa, int* __restrict__ counter) {
+// (Round 5 measured the merge inside this kernel — last block to finish, agent-scope fence + ticket counter: the fence pair costs 4-17 us per launch,
+// more than the launch it saves, and the L2 write-back / invalidate slows the OTHER lane's convolutions: encode 0.190 -> 0.221 s.  Deleted;
+// profiles/EXPERIMENTS.md.)
+__global__ __launch_bounds__(GN_PT) void groupnorm_partial_kernel(const unsigned short* __restrict__ x, int V, int C, int G, int vpb,
+                                                                  double* __restrict__ part) {
     __shared__ float red[GN_PT][17];                 // (sum[8], sumsq[8]) per thread, padded against bank conflicts
-    __shared__ float sh_mu[64], sh_rstd[64];
-    __shared__ int sh_last;
     const int nb = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
     const int oct_per_vox = C >> 3;                  // 16-byte pieces per voxel (divides 256)
     const int tid = threadIdx.x;
@@ -102,25 +97,15 @@ __global__ __launch_bounds__(GN_PT) void groupnorm_partial_kernel(const unsigned
         }
         __syncthreads();
     }
-    double* part_nb = part + (size_t)nb * nblk * fa.G * 2;
-    if (tid < fa.G) {                                 // channels of group tid, in channel order, in double
-        const int cpg = C / fa.G;
+    if (tid < G) {                                    // channels of group tid, in channel order, in double
+        const int cpg = C / G;
         double ds = 0.0, dq = 0.0;
         for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { ds += (double)red[c >> 3][c & 7]; dq += (double)red[c >> 3][8 + (c & 7)]; }
-        *(double2*)(part_nb + ((size_t)blk * fa.G + tid) * 2) = make_double2(ds, dq);
-        if (FUSED) __threadfence();                   // release (the writing wave only): this block's partial row before its ticket
+        *(double2*)(part + (((size_t)nb * nblk + blk) * G + tid) * 2) = make_double2(ds, dq);
     }
-    if (!FUSED) return;
-    __syncthreads();
-    if (tid == 0) sh_last = (atomicAdd(&counter[nb], 1) == nblk - 1);
-    __syncthreads();
-    if (!sh_last) return;
-    __threadfence();                                  // acquire: every other block's row
-    groupnorm_finalize_block(part_nb, nblk, nb, fa, reinterpret_cast<double(*)[2]>(&red[0][0]), sh_mu, sh_rstd);
-    if (tid == 0) counter[nb] = 0;                    // ready for the next launch on this counter (stream order / graph replay)
 }
 
-// The two-launch form (counter == NULL): the same tail as its own kernel, one workgroup per batch item -> bit-identical to the fused form.
+// Second launch: the merge, one workgroup per batch item.
 __global__ __launch_bounds__(GN_PT) void groupnorm_finalize_kernel(const double* __restrict__ part, int nblk, GnFinalArgs fa) {
     __shared__ double sh[GN_PT][2];
     __shared__ float sh_mu[64], sh_rstd[64];
@@ -177,6 +162,7 @@ struct GnApplyArgs {
     int causal;
     const unsigned short* front_prev;
     unsigned short* front_next;
+    int nt;                                               // A/B (AETHER_GN_NT=1): non-temporal loads of x / stores of y
 };
 
 // One workgroup per (t, h) row of one batch item.  A thread owns one channel octet (256 % (C/8) == 0, so the octet of item
@@ -208,8 +194,13 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(GnApplyArgs p) {
         const int wb = u >> p.log2_opv;
         const size_t off = (size_t)(wb * RW) * p.C + c0;
         u16x8 raw[RW];
+        if (p.nt) {
 #pragma unroll
-        for (int k = 0; k < RW; ++k) raw[k] = *(const u16x8*)(xrow + off + (size_t)k * p.C);
+            for (int k = 0; k < RW; ++k) raw[k] = __builtin_nontemporal_load((const u16x8*)(xrow + off + (size_t)k * p.C));
+        } else {
+#pragma unroll
+            for (int k = 0; k < RW; ++k) raw[k] = *(const u16x8*)(xrow + off + (size_t)k * p.C);
+        }
         f32x4 y0, y1, b0, b1;
         if (crow != nullptr) {
             const float* cv = crow + (size_t)(wb >> p.log2_cw) * 2 * p.C;
@@ -233,7 +224,8 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(GnApplyArgs p) {
                 for (int e = 0; e < 8; ++e) o[e] = silu(o[e]);
             }
             const uint4 ov = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
-            *(uint4*)(yrow + off + (size_t)k * p.C) = ov;
+            if (p.nt) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, ov), (u32x4*)(yrow + off + (size_t)k * p.C));
+            else *(uint4*)(yrow + off + (size_t)k * p.C) = ov;
             if (p.causal) {
                 const size_t vo = off + (size_t)k * p.C;
                 if (t == 0 && p.front_prev == nullptr) {             // first chunk: the two front frames replicate frame 0
@@ -291,21 +283,17 @@ using namespace aether;
 #define AE_STREAM ((hipStream_t)stream)
 
 extern "C" int aether_groupnorm_stats(const void* x, int NB, int V, int C, int G, float eps, const float* gamma, const float* beta,
-                                      float* partial_ws, int nblk, float* stats, float* affine, int* counter, void* stream) {
+                                      float* partial_ws, int nblk, float* stats, float* affine, void* stream) {
     if (!x || !partial_ws || !stats || !affine || !gamma || !beta) return aether_set_error(AETHER_ERR_ARG, "groupnorm_stats: null pointer");
     if (C % 8 != 0 || C > 2048 || 256 % (C / 8) != 0 || C % G != 0 || G > 64 || 256 % G != 0 || C < 2 * G)
         return aether_set_error(AETHER_ERR_SHAPE, "groupnorm_stats: unsupported C/G");
     if (nblk <= 0 || NB <= 0 || V <= 0) return aether_set_error(AETHER_ERR_ARG, "groupnorm_stats: bad sizes");
-    if (((uintptr_t)partial_ws & 15) || ((uintptr_t)counter & 3)) return aether_set_error(AETHER_ERR_ALIGN, "groupnorm_stats: partial_ws must be 16-byte aligned");
+    if ((uintptr_t)partial_ws & 15) return aether_set_error(AETHER_ERR_ALIGN, "groupnorm_stats: partial_ws must be 16-byte aligned");
     const int vpb = (V + nblk - 1) / nblk;
     const int nblk_eff = (V + vpb - 1) / vpb;
     GnFinalArgs fa = {C, G, V, eps, gamma, beta, stats, affine};
     double* part = reinterpret_cast<double*>(partial_ws);           // [NB, nblk_eff, G, 2] doubles: 16 G <= 8 C bytes per block
-    if (counter != nullptr) {
-        hipLaunchKernelGGL(groupnorm_partial_kernel<true>, dim3(nblk_eff, NB), dim3(GN_PT), 0, AE_STREAM, (const unsigned short*)x, V, C, vpb, part, fa, counter);
-        return aether_check_launch("groupnorm_stats (fused)");
-    }
-    hipLaunchKernelGGL(groupnorm_partial_kernel<false>, dim3(nblk_eff, NB), dim3(GN_PT), 0, AE_STREAM, (const unsigned short*)x, V, C, vpb, part, fa, nullptr);
+    hipLaunchKernelGGL(groupnorm_partial_kernel, dim3(nblk_eff, NB), dim3(GN_PT), 0, AE_STREAM, (const unsigned short*)x, V, C, G, vpb, part);
     int rc = aether_check_launch("groupnorm_partial");
     if (rc) return rc;
     hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(NB), dim3(GN_PT), 0, AE_STREAM, part, nblk_eff, fa);
@@ -355,6 +343,8 @@ static int groupnorm_apply_impl(const void* x, int NB, int T, int H, int W, int 
     const int npass = (units + 255) / 256;
     int bd = ((units + npass - 1) / npass + opv - 1) / opv * opv;
     static const bool fixed256 = [] { const char* e = getenv("AETHER_GN_APPLY_FIXED_BLOCK"); return e && e[0] == '1'; }();     // A/B switch
+    static const bool nt = [] { const char* e = getenv("AETHER_GN_NT"); return e && e[0] == '1'; }();
+    p.nt = nt ? 1 : 0;
     if (fixed256 || bd > 256 || bd < 64) bd = 256;
     const dim3 grid(T * H, NB), block(bd);
     switch (rw) {

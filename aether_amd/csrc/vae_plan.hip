@@ -12,7 +12,6 @@
 #include <math.h>
 #include <algorithm>
 #include <stdint.h>
-#include <stdlib.h>
 #include <map>
 #include <string>
 #include <tuple>
@@ -34,9 +33,6 @@ struct NormW {
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 typedef std::tuple<int, int, int, int, int, int> Shape5;   // (lane, NB, T, H, W, C)
-
-constexpr int kGnCounterSlots = 4096;                      // GroupNorm calls of one encode / decode (480x720: 580 / 740)
-constexpr size_t kGnCounterBytes = (size_t)kGnCounterSlots * 4 * sizeof(int);
 
 }  // namespace
 
@@ -185,10 +181,6 @@ struct Plan {
     hipStream_t lane_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     float* lane_splitk[4] = {nullptr, nullptr, nullptr, nullptr};
     void set_lane(int l) { lane = l; stream = lane_stream[l]; splitk = lane_splitk[l]; }
-    // ticket counters of the fused GroupNorm statistics (aether_groupnorm_stats): 4 ints per GroupNorm call of this run, zeroed once at the start of
-    // the run and left zero by every launch; null = two launches per GroupNorm (AETHER_VAE_GN_TWO_LAUNCH=1, the A/B switch)
-    int* gn_counters = nullptr;
-    int gn_next = 0;
     int rc = 0;
     std::string err;
 
@@ -273,12 +265,7 @@ struct Plan {
         if (nw.spatial()) cond = (float*)alloc((size_t)zq->NB * zq->T * zq->H * zq->W * 2 * x.C * 4);
         char* vol = padded(x.NB, x.T + pad_t, x.H + 2 * pad_hw, x.W + 2 * pad_hw, x.C);
         if (dry || rc) return vol;
-        int* counter = nullptr;
-        if (gn_counters != nullptr) {
-            if (gn_next >= kGnCounterSlots || x.NB > 4) { fail(AETHER_ERR_SHAPE, "vae: internal: GroupNorm ticket counters exhausted"); return vol; }
-            counter = gn_counters + 4 * gn_next++;
-        }
-        if (!ok(aether_groupnorm_stats(x.p, x.NB, V, x.C, G, nw.spatial() ? 1e-6f : eps, nw.gamma, nw.beta, part, nblk, stats, affine, counter, stream),
+        if (!ok(aether_groupnorm_stats(x.p, x.NB, V, x.C, G, nw.spatial() ? 1e-6f : eps, nw.gamma, nw.beta, part, nblk, stats, affine, stream),
                 "aether_groupnorm_stats")) return vol;
         if (nw.spatial()) {
             if (!ok(aether_spatial_cond(zq->p, zq->NB, zq->T * zq->H * zq->W, zq->C, x.C, nw.wy, nw.by, nw.wb, nw.bb, cond, stream), "aether_spatial_cond"))
@@ -620,7 +607,6 @@ int vae_run(AetherVae* h, bool decode, const void* src, int T, int H, int W, int
     Plan dry; dry.h = h; dry.stream = nullptr; dry.dry = true; dry.n_lanes = NL;
     int oT, oH, oW;
     dry.alloc(NL * kVaeSplitKBytes);
-    dry.alloc(kGnCounterBytes);
     if (!dry.run(decode, src, T, H, W, tiling, nullptr, &oT, &oH, &oW)) return aether_set_error(dry.rc, dry.err.c_str());
     const size_t pool_total = h->pool_bytes + dry.pool_need;
     const size_t need = align_up(pool_total, 256) + dry.peak;
@@ -630,7 +616,7 @@ int vae_run(AetherVae* h, bool decode, const void* src, int T, int H, int W, int
     if (h->ws != (char*)workspace || h->ws_bytes != workspace_bytes) {        // a new workspace: the tap tables have to be generated in it again
         h->ws = (char*)workspace; h->ws_bytes = workspace_bytes;
         h->pool.clear(); h->taps.clear(); h->pool_bytes = 0;
-        Plan d2; d2.h = h; d2.dry = true; d2.n_lanes = NL; d2.alloc(NL * kVaeSplitKBytes); d2.alloc(kGnCounterBytes);
+        Plan d2; d2.h = h; d2.dry = true; d2.n_lanes = NL; d2.alloc(NL * kVaeSplitKBytes);
         if (!d2.run(decode, src, T, H, W, tiling, nullptr, &oT, &oH, &oW)) return aether_set_error(d2.rc, d2.err.c_str());
         if (align_up(d2.pool_need, 256) + d2.peak > workspace_bytes) return aether_set_error(AETHER_ERR_ARG, "vae: workspace too small");
     }
@@ -654,14 +640,6 @@ int vae_run(AetherVae* h, bool decode, const void* src, int T, int H, int W, int
     }
     for (int k = 0; k < NL; ++k) p.lane_splitk[k] = (float*)p.alloc(kVaeSplitKBytes);
     p.splitk_bytes = kVaeSplitKBytes;
-    {
-        int* counters = (int*)p.alloc(kGnCounterBytes);
-        const char* two = getenv("AETHER_VAE_GN_TWO_LAUNCH");
-        if (!(two && two[0] == '1')) {
-            if (hipMemsetAsync(counters, 0, kGnCounterBytes, (hipStream_t)stream) != hipSuccess) return aether_set_error(AETHER_ERR_LAUNCH, "vae: could not zero the GroupNorm ticket counters");
-            p.gn_counters = counters;
-        }
-    }
     p.set_lane(0);
     if (!p.run(decode, src, T, H, W, tiling, out, &oT, &oH, &oW)) return aether_set_error(p.rc, p.err.c_str());
     return AETHER_OK;

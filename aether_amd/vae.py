@@ -501,11 +501,8 @@ class AetherVAE:
         stats = torch.empty(NB * G * 2, dtype=torch.float32, device=self.device)
         affine = torch.empty(NB * 2 * Cc, dtype=torch.float32, device=self.device)
         eps = 1e-6 if (eps is None or norm.spatial) else eps
-        if getattr(self, "_gn_counter", None) is None:       # ticket counters of the one-launch statistics: zero on entry, left zero by every launch
-            self._gn_counter = torch.zeros(16, dtype=torch.int32, device=self.device)
         _lib.check(self._lib.aether_groupnorm_stats(x.data_ptr(), NB, V, Cc, G, float(eps), norm.gamma.data_ptr(), norm.beta.data_ptr(),
-                                                    part.data_ptr(), nblk, stats.data_ptr(), affine.data_ptr(), self._gn_counter.data_ptr(),
-                                                    self._stream()),
+                                                    part.data_ptr(), nblk, stats.data_ptr(), affine.data_ptr(), self._stream()),
                    "aether_groupnorm_stats")
         vol = self._padded((NB, T + pad_t, H + 2 * pad_hw, W + 2 * pad_hw, Cc))
         cond, tmap, zT, zH, zW = None, None, 0, 0, 0

@@ -166,12 +166,9 @@ int aether_im2col_first(const void* x, long sC, long sT, long sH, long sW, int C
 /* GroupNorm statistics of x [NB, V, C] -> stats fp32 [NB, G, 2] = (mean, rstd) and the folded per-channel affine
  * table affine fp32 [NB, 2, C] (scale = rstd*gamma, shift = beta - mean*rstd*gamma).  Deterministic: per-block
  * per-group partial sums in double (partial_ws: NB*nblk*2*C floats of 16-byte aligned scratch, used as [NB, nblk, G, 2]
- * doubles; needs C >= 2 G) merged in a fixed order in double.  counter: NULL = two launches (partial sums, then the
- * merge); or device int[NB], ALL ZERO on entry and left zero: ONE launch, the last block to finish for a batch item
- * (agent-scope fence + ticket) does the merge.  A counter must not be shared by launches that can run concurrently.
- * Both forms give bit-identical results. */
+ * doubles; needs C >= 2 G) merged in a fixed order in double by a second launch. */
 int aether_groupnorm_stats(const void* x, int NB, int V, int C, int G, float eps, const float* gamma, const float* beta,
-                           float* partial_ws, int nblk, float* stats, float* affine, int* counter, void* stream);
+                           float* partial_ws, int nblk, float* stats, float* affine, void* stream);
 
 /* CogVideoXSpatialNorm3D conditioning at LATENT resolution (nearest up-sampling commutes with a 1x1x1 conv):
  * cond fp32 [NB, zV, 2, C]: [.,.,0,:] = conv_y(zq), [.,.,1,:] = conv_b(zq); zq bf16 [NB, zV, zC] channels-last;

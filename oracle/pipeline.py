@@ -16,14 +16,16 @@ from einops import rearrange
 @torch.no_grad()
 def sample(task, transformer, vae, scheduler, prompt_embeds, *, image=None, goal=None, video=None, raymap=None, height, width,
            num_frames, num_inference_steps=None, guidance_scale=None, use_dynamic_cfg=False, generator=None, fps=12,
-           rope=None, dtype=torch.bfloat16, device="cpu", compute_dtype=None, trace=None, vae_device=None):
+           rope=None, dtype=torch.bfloat16, device="cpu", compute_dtype=None, trace=None, vae_device=None, video_latents=None):
     """image/goal: [1,3,H,W] in [-1,1]; video: [F,3,H,W]; raymap: [1,F,6,h,w]. Returns (rgb, disparity, raymap) tensors.
     compute_dtype (calibration only): run the three modules in this dtype (e.g. fp32 weights) while every random draw
     and every inter-module tensor keeps the reference dtype `dtype`, so runs at different precision see the SAME noise.
     trace (fixture generation only): a dict that receives the intermediates a full-size fixture records — the video posterior,
     `condition_latents`, every step's noise prediction, the final latents and the raw decoder outputs.
     device / vae_device (fixture generation on an accelerator, tools/make_fullsize_golden_gpu.py): where the transformer / the VAE live; every random
-    draw is still made on the generator's device (CPU) and moved, as `randn_tensor` does (P:683), so the noise is the same on every device."""
+    draw is still made on the generator's device (CPU) and moved, as `randn_tensor` does (P:683), so the noise is the same on every device.
+    video_latents (same tool): the sampled + scaled video latents [1, f, 16, h, w] of an EARLIER run of this function on the same video and seed
+    (trace["condition_latents"][:, :, :16]); the posterior draw is still made, so the generator stays aligned, but the 41-frame encode is skipped."""
     cd = compute_dtype or dtype
     dev = torch.device(device)
     vdev = torch.device(vae_device) if vae_device is not None else dev
@@ -55,7 +57,10 @@ def sample(task, transformer, vae, scheduler, prompt_embeds, *, image=None, goal
         image_latents = enc(image.to(dtype).unsqueeze(2))
     if goal is not None:
         goal_latents = enc(goal.to(dtype).unsqueeze(2))
-    if video is not None:
+    if video is not None and video_latents is not None:
+        torch.randn((1, 16, lat_frames, height // 8, width // 8), generator=generator, dtype=dtype)    # the posterior draw of `enc`, discarded
+        video_latents = video_latents.to(dev, dtype)
+    elif video is not None:
         video_latents = enc(video.to(dtype).unsqueeze(0).permute(0, 2, 1, 3, 4))
     if image is not None and goal is None:                                                            # P:633-640
         pad = torch.zeros(1, lat_frames - 1, *image_latents.shape[2:], dtype=dtype, device=dev)

@@ -238,9 +238,13 @@ def test_headline_reconstruction_fifty_steps(cuda, modules):
 # the 10.5-hour CPU run of the same call, profiles/r05_prediction50_cpu_vs_device_oracle.json), final decodes by the fp32 CPU oracle VAE
 # (tools/make_fullsize_golden.py decode50).  Bounds: the bf16 ORACLE's own distance to the same fixture along the same trajectory
 # (profiles/r05_bf16_oracle_calibration_guided50.json) where it is larger than 1.3 x measured, else 1.3 x measured (profiles/r05_parity_fullsize.log).
+# measured on MI355X (profiles/r05_parity_fullsize.log): prediction: 9.1e-4 after step 0, 5.9e-3 after 15, 9.2e-3 after 25, 1.35e-2 after 45, final 1.331e-2 /
+# 2.26 %; planning: final 1.386e-2 / 2.63 %, largest along the trajectory 1.45e-2.  The bf16 ORACLE on the same trajectories: final 1.424e-2 / 2.58 % and
+# 1.470e-2 / 2.96 % (transformer alone in bf16: 1.423e-2 / 1.469e-2) — `ref_rel` / `ref_linf`: the native path must not be further from the fp32 oracle
+# than the reference dtype itself is.  `lat_rel` = 1.1 x the largest value measured along the trajectory.
 GUIDED50_BOUNDS = {
-    "prediction": dict(lat_rel=None, lat_linf=None, psnr=None, disp_rel=None),
-    "planning": dict(lat_rel=None, lat_linf=None, psnr=None, disp_rel=None),
+    "prediction": dict(lat_rel=1.49e-2, ref_rel=1.424e-2, ref_linf=0.0258, psnr=None, disp_rel=None),
+    "planning": dict(lat_rel=1.60e-2, ref_rel=1.470e-2, ref_linf=0.0296, psnr=None, disp_rel=None),
 }
 
 
@@ -276,8 +280,7 @@ def test_guided_call_fifty_steps(cuda, modules, task):
         msg += f"; rgb PSNR {p_rgb:.1f} dB; disparity rel-L2 {m_disp['rel_l2']:.3e}"
     print(msg)
     assert out.rgb.shape == (fc.FRAMES, fc.HEIGHT, fc.WIDTH, 3) and np.isfinite(out.rgb).all() and np.isfinite(out.disparity).all()
-    if bd["lat_rel"] is not None:
-        assert max(errs) <= bd["lat_rel"] and fin["rel_l2"] <= bd["lat_rel"] and fin["linf_rel"] <= bd["lat_linf"], (errs, fin)
+    assert max(errs) <= bd["lat_rel"] and fin["rel_l2"] <= bd["ref_rel"] and fin["linf_rel"] <= bd["ref_linf"], (errs, fin)
     if p_rgb is not None and bd["psnr"] is not None:
         assert p_rgb >= bd["psnr"] and m_disp["rel_l2"] <= bd["disp_rel"], (p_rgb, m_disp)
 
@@ -298,3 +301,45 @@ def test_seventeen_frame_clip_full_size(cuda, modules):
         assert o.rgb.shape == (F, fc.HEIGHT, fc.WIDTH, 3) and o.disparity.shape == (F, fc.HEIGHT, fc.WIDTH) and o.raymap.shape == (F, 6, fc.LAT_H, fc.LAT_W)
         assert np.isfinite(o.rgb).all() and np.isfinite(o.disparity).all() and np.isfinite(o.raymap).all() and float(o.rgb.std()) > 1e-3
         assert np.array_equal(o.rgb, outs[1].rgb) and np.array_equal(o.raymap, outs[1].raymap), f"{task}: two runs with one seed differ"
+
+
+# ---- the reconstruction trajectories under DEVICE semantics ------------------------------------------------------------------------------------------
+# The CPU-generated trajectory fixtures above (fullsize_clip / _traj / _traj50 / _prediction / _planning) contain an artefact of torch-CPU: in
+# `m1 * sample` and `m_noise * noise` (bf16 tensor times python / 0-dim scalar, diffusers' DPM update) the CPU kernels round the SCALAR to bf16 before the
+# multiplication, a CUDA / HIP device keeps it in fp32.  The reference runs on the device (D:218), the native `aether_dpm_step` is bit-identical to the
+# device op sequence — so every step of a CPU-oracle trajectory carries a perturbation of up to 2^-9 on two coefficients that neither the reference nor the
+# native path has (profiles/r05_prediction50_cpu_vs_device_oracle.json: the same fp32 oracle on CPU and on the device differs by 2.6e-3 after TWO steps,
+# 20 % of the bf16 latents by one ulp).  These fixtures are the same call, same oracle, same seed, with the transformer and the scheduler update executed by
+# torch on the device (tools/make_fullsize_golden_gpu.py recon4 recon10 recon50); decodes by the fp32 CPU oracle VAE.
+RECON_DEVICE_BOUNDS = {4: None, 10: None, 50: None}
+
+
+@pytest.mark.parametrize("steps", [4, 10, 50])
+def test_reconstruction_against_device_oracle(cuda, modules, steps):
+    """configs[1] (50 steps), the reference default (4 steps) and the 10-step trajectory against the fp32 oracle under the reference's (device) semantics of
+    the scheduler update: latents after every kept step, final latents, decoded rgb / disparity when the fixture carries them."""
+    path = os.path.join(fc.GOLDEN_DIR, f"fullsize_recon{steps}_device.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not generated (tools/make_fullsize_golden_gpu.py recon{steps})")
+    dit, vae = modules
+    z, meta = _load(f"fullsize_recon{steps}_device.npz")
+    pipe = _pipeline(dit, vae)
+    kept = list(meta["kept_steps"])
+    out, rec = _trajectory(pipe, steps, set(kept))
+    errs = [fc.metrics(rec[i].to(torch.bfloat16).float(), fc.from_bf16_bits(z["step_latents_s6"][k]).float())["rel_l2"] for k, i in enumerate(kept)]
+    fin = fc.metrics(pipe._final_latents.cpu().float(), fc.from_bf16_bits(z["final_latents_bits"]).float())
+    msg = (f"\n[fullsize] reconstruction, {steps} steps, vs the fp32 oracle under DEVICE semantics: latents rel-L2 after steps " + ", ".join(f"{i}: {e:.2e}" for i, e in zip(kept, errs))
+           + f"; final: rel-L2 {fin['rel_l2']:.3e}  L-inf {fin['linf']:.4f} ({100 * fin['linf_rel']:.2f} % of max|ref| {fin['ref_max']:.2f})")
+    s = fc.DEC_STRIDE
+    p_rgb = m_disp = None
+    if "rgb_s8" in z.files:
+        p_rgb = fc.psnr(torch.from_numpy(out.rgb)[:, ::s, ::s], torch.from_numpy(z["rgb_s8"].astype(np.float32)))
+        m_disp = fc.metrics(torch.from_numpy(out.disparity)[:, ::s, ::s], torch.from_numpy(z["disparity_s8"].astype(np.float32)))
+        msg += f"; rgb PSNR {p_rgb:.1f} dB; disparity rel-L2 {m_disp['rel_l2']:.3e}"
+    print(msg)
+    assert np.isfinite(out.rgb).all() and np.isfinite(out.disparity).all()
+    bd = RECON_DEVICE_BOUNDS[steps]
+    if bd is not None:
+        assert max(errs) <= bd["lat_rel"] and fin["rel_l2"] <= bd["lat_rel"] and fin["linf_rel"] <= bd["lat_linf"], (errs, fin)
+        if p_rgb is not None and bd.get("psnr") is not None:
+            assert p_rgb >= bd["psnr"] and m_disp["rel_l2"] <= bd["disp_rel"], (p_rgb, m_disp)

@@ -328,16 +328,8 @@ def test_groupnorm_run_lengths_and_long_blocks(cuda, hip_lib, Cc, W, zW, nblk):
     stats = torch.empty(NB, G, 2, dtype=torch.float32, device=cuda)
     affine = torch.empty(NB, 2, Cc, dtype=torch.float32, device=cuda)
     st = _lib.current_stream()
-    # one launch (ticket counter: last block merges) and two launches (counter = NULL) must agree bit for bit; the counter is left zero
-    counter = torch.zeros(NB, dtype=torch.int32, device=cuda)
-    stats2, affine2 = torch.empty_like(stats), torch.empty_like(affine)
     _lib.check(hip_lib.aether_groupnorm_stats(xs.data_ptr(), NB, V, Cc, G, 1e-6, gamma.data_ptr(), beta.data_ptr(), part.data_ptr(), nblk,
-                                              stats2.data_ptr(), affine2.data_ptr(), None, st), "stats (two launches)")
-    for _ in range(3):                                    # re-use of the self-resetting counter
-        stats.fill_(float("nan")); affine.fill_(float("nan"))
-        _lib.check(hip_lib.aether_groupnorm_stats(xs.data_ptr(), NB, V, Cc, G, 1e-6, gamma.data_ptr(), beta.data_ptr(), part.data_ptr(), nblk,
-                                                  stats.data_ptr(), affine.data_ptr(), counter.data_ptr(), st), "stats")
-        assert torch.equal(stats, stats2) and torch.equal(affine, affine2) and int(counter.abs().sum()) == 0
+                                              stats.data_ptr(), affine.data_ptr(), st), "stats")
     xg = x.double().reshape(NB, V, G, Cc // G)
     mu = xg.mean(dim=(1, 3))
     var = xg.var(dim=(1, 3), unbiased=False)

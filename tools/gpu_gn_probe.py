@@ -52,18 +52,14 @@ def main():
         stats = torch.empty(NB * G * 2, dtype=torch.float32, device=dev)
         affine = torch.empty(NB * 2 * Cc, dtype=torch.float32, device=dev)
         lib, st = vae._lib, vae._stream()
-        timed("stats(partial+finalize, two launches)", lambda: lib.aether_groupnorm_stats(x.data_ptr(), NB, V, Cc, G, 1e-6, norm.gamma.data_ptr(), norm.beta.data_ptr(),
-                                                                            part.data_ptr(), nblk, stats.data_ptr(), affine.data_ptr(), None, st))
-        counter = torch.zeros(16, dtype=torch.int32, device=dev)
-        timed("stats(one launch, last block merges)", lambda: lib.aether_groupnorm_stats(x.data_ptr(), NB, V, Cc, G, 1e-6, norm.gamma.data_ptr(), norm.beta.data_ptr(),
-                                                                            part.data_ptr(), nblk, stats.data_ptr(), affine.data_ptr(), counter.data_ptr(), st))
+        timed("stats(partial+finalize)", lambda: lib.aether_groupnorm_stats(x.data_ptr(), NB, V, Cc, G, 1e-6, norm.gamma.data_ptr(), norm.beta.data_ptr(),
+                                                                            part.data_ptr(), nblk, stats.data_ptr(), affine.data_ptr(), st))
         timed("norm_to_padded(stats+cond+apply)", lambda: vae._norm_to_padded(x, norm, 2, 1, True, zq, 1e-6))
         vol = vae._norm_to_padded(x, norm, 2, 1, True, zq, 1e-6)
         timed("causal_front", lambda: vae._causal_front(vol, cache, "k"))
         nbytes = x.numel() * 2
-        prof["stats_GBps"] = nbytes / prof["stats(one launch, last block merges)"] / 1e3
-        prof["stats_two_launch_GBps"] = nbytes / prof["stats(partial+finalize, two launches)"] / 1e3
-        apply_us = prof["norm_to_padded(stats+cond+apply)"] - prof["stats(one launch, last block merges)"]
+        prof["stats_GBps"] = nbytes / prof["stats(partial+finalize)"] / 1e3
+        apply_us = prof["norm_to_padded(stats+cond+apply)"] - prof["stats(partial+finalize)"]
         prof["apply+cond_us"] = apply_us
         prof["apply_GBps"] = 2 * nbytes / apply_us / 1e3
         out.append(dict(shape=shp, MB=nbytes / 1e6, **{k: round(v, 1) for k, v in prof.items()}))

@@ -45,7 +45,7 @@ def main():
             torch.cuda.synchronize()
             times.append(time.perf_counter() - t0)
         t = min(times)
-        res[name] = {"lanes": args.lanes, "gn_two_launch": os.environ.get("AETHER_VAE_GN_TWO_LAUNCH", "0"), "seconds": t, "TFLOPs_algorithmic": flop / t / 1e12, "frac_mfma_peak": flop / t / 2.5e15,
+        res[name] = {"lanes": args.lanes, "seconds": t, "TFLOPs_algorithmic": flop / t / 1e12, "frac_mfma_peak": flop / t / 2.5e15,
                      "out_shape": list(out.shape), "finite": bool(torch.isfinite(out.float()).all()), "out_std": float(out.float().std())}
         print(name, res[name], flush=True)
     res["peak_mem_GB"] = torch.cuda.max_memory_allocated() / 1e9

@@ -228,6 +228,47 @@ def stage_calib(dit32, runs):
                                "trajectories on the named inputs, dynamic CFG, identical noise and condition latents", **res}, f, indent=1)
 
 
+def stage_recon(dit, steps, name, keep):
+    """The RECONSTRUCTION call of tools/make_fullsize_golden.py (stage_clip / stage_traj: same clip, seed CLIP_SEED, same posterior sample — the sampled
+    video latents come from tests/golden/fullsize_clip_condition.npz, written by the fp32 CPU oracle VAE in the build container) with the fp32 oracle
+    transformer on the device: B = 1, no guidance, `steps` steps.  Same oracle code as the CPU fixtures; the difference is where torch executes the
+    scheduler's element-wise update: a CUDA / HIP device keeps the python scalars of `m1 * sample` and `m_noise * noise` in fp32 (what the reference,
+    which runs on the device, does: D:218), torch-CPU rounds them to bf16 first — a per-step perturbation of up to 2^-9 that is in every CPU-generated
+    trajectory fixture and in neither the reference nor the native path."""
+    from aether_amd.scheduler import CogVideoXDPMScheduler
+    from oracle.pipeline import sample
+    zc = np.load(os.path.join(fc.GOLDEN_DIR, "fullsize_clip_condition.npz"))
+    video_latents = fc.from_bf16_bits(zc["video_latents_bits"])
+    v = fc.video_as_model_input(fc.clip_video())
+    step_lat, times, mark = {}, [], [time.perf_counter()]
+    trace = {}
+
+    vae = host_vae()                                                  # only its config and the (unused here) decode stub are touched
+
+    def on_step(i, latents):
+        _sync()
+        now = time.perf_counter()
+        times.append(now - mark[0])
+        mark[0] = now
+        trace["noise_pred"].clear()
+        if i in keep:
+            step_lat[i] = fc.bf16_bits(latents[:, :, :, ::6, ::6].cpu())
+
+    trace["on_step"] = on_step
+    t0 = time.perf_counter()
+    sample("reconstruction", dit, vae, CogVideoXDPMScheduler(), fc.prompt_embeds(), video=v, height=fc.HEIGHT, width=fc.WIDTH, num_frames=fc.FRAMES,
+           num_inference_steps=steps, generator=torch.Generator().manual_seed(fc.CLIP_SEED), rope=_rope(), compute_dtype=torch.float32, trace=trace,
+           device=DEV, vae_device="cpu", video_latents=video_latents)
+    total = time.perf_counter() - t0
+    kept = sorted(step_lat)
+    meta = dict(task="reconstruction", steps=steps, kept_steps=kept, clip_seed=fc.CLIP_SEED, dit_seed=fc.DIT_SEED, vae_seed=fc.VAE_SEED, step_seconds=times,
+                seconds_total=total, torch=torch.__version__, decoded=False,
+                generated_on=f"fp32 oracle transformer with torch on {_devname()} (tools/make_fullsize_golden_gpu.py); video latents from the fp32 CPU oracle VAE")
+    np.savez_compressed(os.path.join(OUT, name), step_latents_s6=np.stack([step_lat[k] for k in kept]), final_latents_bits=fc.bf16_bits(trace["final_latents"].cpu()),
+                        meta=json.dumps(meta))
+    log(f"reconstruction, {steps} steps: {total:.0f} s on the device; wrote gpurun_out/fixtures/{name}")
+
+
 def stage_calib_full(dit32, tasks):
     """The WHOLE guided call in the reference dtype — bf16 VAE encode of the observation (host CPU, torch's bf16 kernels) AND bf16 transformer — against
     the committed fp32 fixtures (tests/golden/fullsize_<task>50.npz): what `D:218,226` + `P:297` (everything loaded and run as bf16) costs end to end
@@ -269,6 +310,11 @@ def main():
             stage_pin(dit)
             continue
         if st == "calib":
+            continue
+        if st.startswith("recon"):                                 # recon4 / recon10 / recon50: the reconstruction fixtures under device semantics
+            n = int(st[5:])
+            keep = set(fc.HEADLINE_KEEP) if n == fc.HEADLINE_STEPS else set(range(n))
+            stage_recon(dit, n, f"fullsize_recon{n}_device.npz", keep)
             continue
         if st == "calib_full":                                     # needs the committed fixtures; converts the transformer to bf16 in place: LAST stage
             stage_calib_full(dit, ["prediction", "planning"])

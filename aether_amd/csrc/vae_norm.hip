@@ -8,7 +8,6 @@
 //                                 resolution pass only gathers 2 x 8 floats per 16-byte piece
 //   4. groupnorm_apply_kernel     one streaming read of x + one write into the next convolution's zero-bordered
 //                                 input volume:  silu( (x*scale+shift) [* Y(zq) + B(zq)] )
-#include <stdlib.h>
 #include "common.hpp"
 #include "../../include/aether_hip.h"
 
@@ -56,8 +55,7 @@ AE_DEV void groupnorm_finalize_block(const double* __restrict__ part_nb, int nbl
 // and iteration (256 workgroups x 1024 x 64 B = 16 MiB outstanding on the whole chip).  Per block: per-channel fp32 (sum, sum of squares) by a
 // fixed-shape LDS tree, folded to per-GROUP doubles part[nb, blk, g, (sum, sumsq)] in channel order.
 // (Round 5 measured the merge inside this kernel — last block to finish, agent-scope fence + ticket counter: the fence pair costs 4-17 us per launch,
-// more than the launch it saves, and the L2 write-back / invalidate slows the OTHER lane's convolutions: encode 0.190 -> 0.221 s.  Deleted;
-// profiles/EXPERIMENTS.md.)
+// more than the launch it saves; whole encode / decode 2-3 % slower with one or two lanes.  Deleted; profiles/EXPERIMENTS.md.)
 __global__ __launch_bounds__(GN_PT) void groupnorm_partial_kernel(const unsigned short* __restrict__ x, int V, int C, int G, int vpb,
                                                                   double* __restrict__ part) {
     __shared__ float red[GN_PT][17];                 // (sum[8], sumsq[8]) per thread, padded against bank conflicts
@@ -162,7 +160,6 @@ struct GnApplyArgs {
     int causal;
     const unsigned short* front_prev;
     unsigned short* front_next;
-    int nt;                                               // A/B (AETHER_GN_NT=1): non-temporal loads of x / stores of y
 };
 
 // One workgroup per (t, h) row of one batch item.  A thread owns one channel octet (256 % (C/8) == 0, so the octet of item
@@ -194,13 +191,8 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(GnApplyArgs p) {
         const int wb = u >> p.log2_opv;
         const size_t off = (size_t)(wb * RW) * p.C + c0;
         u16x8 raw[RW];
-        if (p.nt) {
 #pragma unroll
-            for (int k = 0; k < RW; ++k) raw[k] = __builtin_nontemporal_load((const u16x8*)(xrow + off + (size_t)k * p.C));
-        } else {
-#pragma unroll
-            for (int k = 0; k < RW; ++k) raw[k] = *(const u16x8*)(xrow + off + (size_t)k * p.C);
-        }
+        for (int k = 0; k < RW; ++k) raw[k] = *(const u16x8*)(xrow + off + (size_t)k * p.C);
         f32x4 y0, y1, b0, b1;
         if (crow != nullptr) {
             const float* cv = crow + (size_t)(wb >> p.log2_cw) * 2 * p.C;
@@ -224,8 +216,7 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(GnApplyArgs p) {
                 for (int e = 0; e < 8; ++e) o[e] = silu(o[e]);
             }
             const uint4 ov = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
-            if (p.nt) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, ov), (u32x4*)(yrow + off + (size_t)k * p.C));
-            else *(uint4*)(yrow + off + (size_t)k * p.C) = ov;
+            *(uint4*)(yrow + off + (size_t)k * p.C) = ov;
             if (p.causal) {
                 const size_t vo = off + (size_t)k * p.C;
                 if (t == 0 && p.front_prev == nullptr) {             // first chunk: the two front frames replicate frame 0
@@ -342,10 +333,7 @@ static int groupnorm_apply_impl(const void* x, int NB, int T, int H, int W, int 
     const int units = (W / rw) << l2, opv = 1 << l2;
     const int npass = (units + 255) / 256;
     int bd = ((units + npass - 1) / npass + opv - 1) / opv * opv;
-    static const bool fixed256 = [] { const char* e = getenv("AETHER_GN_APPLY_FIXED_BLOCK"); return e && e[0] == '1'; }();     // A/B switch
-    static const bool nt = [] { const char* e = getenv("AETHER_GN_NT"); return e && e[0] == '1'; }();
-    p.nt = nt ? 1 : 0;
-    if (fixed256 || bd > 256 || bd < 64) bd = 256;
+    if (bd > 256 || bd < 64) bd = 256;
     const dim3 grid(T * H, NB), block(bd);
     switch (rw) {
         case 8: hipLaunchKernelGGL(groupnorm_apply_kernel<8>, grid, block, 0, AE_STREAM, p); break;

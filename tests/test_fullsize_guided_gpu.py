@@ -243,8 +243,9 @@ def test_headline_reconstruction_fifty_steps(cuda, modules):
 # 1.470e-2 / 2.96 % (transformer alone in bf16: 1.423e-2 / 1.469e-2) — `ref_rel` / `ref_linf`: the native path must not be further from the fp32 oracle
 # than the reference dtype itself is.  `lat_rel` = 1.1 x the largest value measured along the trajectory.
 GUIDED50_BOUNDS = {
-    "prediction": dict(lat_rel=1.49e-2, ref_rel=1.424e-2, ref_linf=0.0258, psnr=None, disp_rel=None),
-    "planning": dict(lat_rel=1.60e-2, ref_rel=1.470e-2, ref_linf=0.0296, psnr=None, disp_rel=None),
+    # decoded clip: prediction 36.5 dB, disparity 2.54e-2 (bounds: - 2 dB, x 1.3); planning: the same bounds, 0.5 dB looser (its latents sit 4 % higher)
+    "prediction": dict(lat_rel=1.49e-2, ref_rel=1.424e-2, ref_linf=0.0258, psnr=34.5, disp_rel=3.3e-2),
+    "planning": dict(lat_rel=1.60e-2, ref_rel=1.470e-2, ref_linf=0.0296, psnr=34.0, disp_rel=3.5e-2),
 }
 
 
@@ -310,13 +311,17 @@ def test_seventeen_frame_clip_full_size(cuda, modules):
 # device op sequence — so every step of a CPU-oracle trajectory carries a perturbation of up to 2^-9 on two coefficients that neither the reference nor the
 # native path has (profiles/r05_prediction50_cpu_vs_device_oracle.json: the same fp32 oracle on CPU and on the device differs by 2.6e-3 after TWO steps,
 # 20 % of the bf16 latents by one ulp).  These fixtures are the same call, same oracle, same seed, with the transformer and the scheduler update executed by
-# torch on the device (tools/make_fullsize_golden_gpu.py recon4 recon10 recon50); decodes by the fp32 CPU oracle VAE.
-RECON_DEVICE_BOUNDS = {4: None, 10: None, 50: None}
+# torch on the device (tools/make_fullsize_golden_gpu.py recon4 recon50); decodes by the fp32 CPU oracle VAE.
+# measured on MI355X (profiles/r05_parity_fullsize.log): 4 steps: 3.6e-3 / 6.6e-3 / 9.7e-3 / 1.06e-2 along the trajectory, final 1.017e-2 / 1.53 % (CPU-semantics
+# fixture: 1.032e-2); 10 steps: final 8.99e-3 (9.49e-3; fixture not committed: 7 MB for one more point of the same curve); 50 steps: 7.4e-4 after step 0, 3.3e-3
+# after 10, 5.2e-3 after 20, 7.8e-3 after 35, 1.04e-2 after 50, final 1.047e-2 / 2.76 % — against 1.354e-2 for the CPU-semantics fixture: a quarter of what round 4
+# reported as the 50-step drift was the oracle's own CPU artefact.  Bounds ~1.3 x measured; the decoded-clip bounds are those of the CPU-semantics tests.
+RECON_DEVICE_BOUNDS = {4: dict(lat_rel=1.38e-2, lat_linf=0.020, psnr=36.8, disp_rel=2.9e-2), 50: dict(lat_rel=1.36e-2, lat_linf=0.036, psnr=34.6, disp_rel=3.4e-2)}
 
 
-@pytest.mark.parametrize("steps", [4, 10, 50])
+@pytest.mark.parametrize("steps", [4, 50])
 def test_reconstruction_against_device_oracle(cuda, modules, steps):
-    """configs[1] (50 steps), the reference default (4 steps) and the 10-step trajectory against the fp32 oracle under the reference's (device) semantics of
+    """configs[1] (50 steps) and the reference default (4 steps) against the fp32 oracle under the reference's (device) semantics of
     the scheduler update: latents after every kept step, final latents, decoded rgb / disparity when the fixture carries them."""
     path = os.path.join(fc.GOLDEN_DIR, f"fullsize_recon{steps}_device.npz")
     if not os.path.exists(path):

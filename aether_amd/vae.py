@@ -496,7 +496,7 @@ class AetherVAE:
         NB, T, H, W, Cc = x.shape
         G = self.config.norm_num_groups
         V = T * H * W
-        nblk = max(1, min(256, (V + 127) // 128))     # partial-sum blocks per tile (finalize merges them serially per group)
+        nblk = max(1, min(256, (V + 127) // 128))     # partial-sum blocks per tile (per-group doubles; one workgroup per tile merges them in a fixed order)
         part = torch.empty(NB * nblk * 2 * Cc, dtype=torch.float32, device=self.device)
         stats = torch.empty(NB * G * 2, dtype=torch.float32, device=self.device)
         affine = torch.empty(NB * 2 * Cc, dtype=torch.float32, device=self.device)

@@ -343,6 +343,32 @@ def windows_run(args, dev, rank, world, dist, transformer=None):
                "gather": f"one dist.gather(dst=0) of device tensors per round of {world} window(s), backend {dist.get_backend()}; "
                          "rank 0 merges round j on a side stream while round j+1 is computed",
                "workload": "configs[4]: long-video reconstruction, 8 windows x 41 frames, stride 24"}
+    # N >= 2: ONE reconstruction clip on two ranks — the two final decodes (40 % of the reference-default 4-step clip) on ranks 0 / 1
+    # (AetherV1PipelineCogVideoX.enable_decode_parallel: replicated encode + loop with equal seeds, rank 0 decodes rgb, rank 1 disparity, one all-gather
+    # of the decoded bf16 clips; bit-identical to one rank).  Compare with `clip.reconstruction_4_steps_reference_default` of the N = 1 line.
+    if world >= 2:
+        pair = dist.new_group([0, 1])                          # collective over all ranks
+        single = None
+        if rank < 2:
+            pipe.keep_outputs_on_device = False
+            pipe.enable_decode_parallel(pair)
+            clip = video[:41]
+
+            def one():
+                return pipe(task="reconstruction", video=clip, height=480, width=720, num_frames=41, num_inference_steps=args.window_steps, fps=12,
+                            generator=torch.Generator(device=dev).manual_seed(42))
+            one()                                              # warm-up
+            dist.barrier(group=pair); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = one()
+            torch.cuda.synchronize(); dist.barrier(group=pair)
+            dt = time.perf_counter() - t0
+            pipe.disable_decode_parallel()
+            assert res.rgb.shape == (41, 480, 720, 3) and np.isfinite(res.rgb).all() and np.isfinite(res.disparity).all()
+            single = {"seconds": dt, "steps": args.window_steps, "ranks": 2,
+                      "workload": "configs[1]-style single clip (41x480x720) over 2 ranks: replicated encode + sampling loop, the two final decodes split (P:931 on rank 0, P:936 on rank 1), one all-gather"}
+        if out is not None:
+            out["single_clip_two_ranks_decode_parallel"] = single
     dist.barrier()
     del pipe, vae
     torch.cuda.empty_cache()

@@ -153,3 +153,41 @@ def test_reference_import_paths_and_calling_conventions():
     assert abs(compute_scale(torch.from_numpy(d1), torch.from_numpy(d0), torch.from_numpy(d1 > 0.1)) - float(GOLD["unit_scale"])) < 1e-5
     img = np.random.default_rng(0).random((50, 72, 3), dtype=np.float32)
     assert imcrop_center([img], 480, 720)[0].shape == (48, 72, 3)
+
+
+def test_deferred_camera_algebra_matches_immediate():
+    """WindowMerger fetches a DEVICE raymap asynchronously and runs the window's camera algebra when its copy has landed — possibly several `add` calls
+    later (run_windows_merged: rank 0 must not wait on the host for a merge).  The queue is exercised here without a GPU: events that report "not yet" for a
+    while, windows added meanwhile; poses, focal lengths and every merged array must equal the immediate form's."""
+    from aether_amd.windows import WindowMerger
+
+    class LateEvent:                                       # a copy that lands after `n` polls
+        def __init__(self, n):
+            self.n = n
+
+        def query(self):
+            self.n -= 1
+            return self.n < 0
+
+        def synchronize(self):
+            self.n = -1
+
+    def run(deferred):
+        wins = _windows()
+        m = WindowMerger(total_frames=19, window_frames=wins[0].rgb.shape[0], frame_hw=(H, W), height=H, width=W, device="cpu", smooth_camera=True,
+                         smooth_method="simple")
+        if deferred:
+            real = m._queue_cameras
+
+            def queue(raymap, t0, ov, first):              # what the CUDA branch appends: (host buffer, event, ...); here the "copy" lands 3 polls late
+                m._pending.append((__import__("torch").from_numpy(raymap.astype(np.float32)), LateEvent(3), t0, ov, first))
+            m._queue_cameras = queue
+            del real
+        for w in wins:
+            m.add(w)
+        if deferred:
+            assert len(m._pending) == len(wins), "nothing may have been drained while the copies were in flight"
+        return m.finish()
+
+    for a, b, what in zip(run(False), run(True), ("rgb", "disparity", "poses", "pointmaps")):
+        assert np.array_equal(a, b), what

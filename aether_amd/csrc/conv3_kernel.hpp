@@ -17,6 +17,7 @@
 // LDS: two A buffers (one per (dt,dh,cb) step) + two W buffers (one per K tile).  Instantiations:
 //     <2,4,4,2>  256x256   (Cout % 256 == 0)     2*40 + 2*32 = 144 KiB
 //     <4,2,3,2>  384x128   (Cout % 128 == 0)     2*56 + 2*16 = 144 KiB
+//     <8,1,2,1>  512x32    (conv_out: 3 output channels padded to 32; round 5)   2*72 + 2*4 = 152 KiB
 #pragma once
 #include "gemm_kernel.hpp"
 
@@ -27,9 +28,9 @@ __global__ __launch_bounds__(512) void conv3_gemm_kernel(GemmArgs p) {
     static_assert(WM * WN == 8, "8 wavefronts per workgroup");
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     constexpr int A_ROUNDS = BM / 64 + 1;                 // 64 extra rows behind the tile: rows m0+BM .. m0+BM+1 are read by taps 1, 2
-    constexpr int W_ROUNDS = BN / 64;
+    constexpr int W_ROUNDS = (BN + 63) / 64;
     constexpr int A_BUF = A_ROUNDS * 8192, W_TILE = BN * 128;
-    static_assert(BM % 64 == 0 && BN % 64 == 0, "tile shape");
+    static_assert(BM % 64 == 0 && (BN % 64 == 0 || BN == 32), "tile shape");
     static_assert(2 * A_BUF + 2 * W_TILE <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) char smem[2 * A_BUF + 2 * W_TILE];
 
@@ -70,6 +71,7 @@ __global__ __launch_bounds__(512) void conv3_gemm_kernel(GemmArgs p) {
     }
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     char* const lds_stage = smem + wave_s * 1024;
+    const bool w_active = (BN >= 64) || (wave_s * 8 < BN);   // BN = 32 (conv_out): waves 0-3 carry the 32 weight rows (wave-uniform)
     const buf_rsrc_t a_rsrc = make_buf_rsrc(p.A, p.a_bytes), w_rsrc = make_buf_rsrc(p.W, p.w_bytes);
 
     const int nk = p.K / GEMM_BK;                         // multiple of 3
@@ -103,8 +105,10 @@ __global__ __launch_bounds__(512) void conv3_gemm_kernel(GemmArgs p) {
         const unsigned a_soff = 2u * (unsigned)__builtin_amdgcn_readfirstlane(p.tap_off[0]);
 #pragma unroll
         for (int r = 0; r < A_ROUNDS; ++r) bglds16(a_rsrc, a_off[r], a_soff, lds_stage + r * 8192);
+        if (w_active) {
 #pragma unroll
-        for (int r = 0; r < W_ROUNDS; ++r) bglds16(w_rsrc, w_off[r], 0u, lds_stage + 2 * A_BUF + r * 8192);
+            for (int r = 0; r < W_ROUNDS; ++r) bglds16(w_rsrc, w_off[r], 0u, lds_stage + 2 * A_BUF + r * 8192);
+        }
     }
     drain_and_barrier();
 
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(512) void conv3_gemm_kernel(GemmArgs p) {
         }
 #pragma unroll
         for (int r = 0; r < W_ROUNDS; ++r) {
-            if (piece * 3 / n_pieces == part) bglds16(w_rsrc, w_off[r], w_soff, wdst + r * 8192);
+            if (w_active && piece * 3 / n_pieces == part) bglds16(w_rsrc, w_off[r], w_soff, wdst + r * 8192);
             ++piece;
         }
     };

@@ -219,7 +219,7 @@ extern "C" int aether_conv_gemm_bf16(const void* X, int NB, int iT, int iH, int 
     // Tap-reuse kernel (conv3_kernel.hpp): 3x3(x3) taps in (dt, dh, channel block, dw) order, unit stride, one-voxel zero border
     // in H and W.  Output rows enumerate the padded plane, so it pays where the border is a small share of the plane.
     if ((flags & AETHER_CONV_TAP_REUSE) && stride_hw == 1 && n_taps % 3 == 0 && iW == oW + 2 && iH == oH + 2 && oH >= 3 &&
-        (iT == oT + 2 || iT == oT) && Cout % 128 == 0 && (long)NB * oT * iH * iW < (1l << 31)) {
+        (iT == oT + 2 || iT == oT) && (Cout % 128 == 0 || Cout == 32) && (long)NB * oT * iH * iW < (1l << 31)) {
         p.M = NB * oT * iH * iW;
         p.ksplit = 1;
 #define LAUNCH_C3(WM_, WN_, MT_, NT_, BM_, BN_)                                                                                     \
@@ -232,7 +232,8 @@ extern "C" int aether_conv_gemm_bf16(const void* X, int NB, int iT, int iH, int 
                    else hipLaunchKernelGGL((conv3_gemm_kernel<WM_, WN_, MT_, NT_, EPI_BIAS, false>), grid, block, 0, AE_STREAM, p); }               \
         } while (0)
         if (Cout % 256 == 0) LAUNCH_C3(2, 4, 4, 2, 256, 256);
-        else LAUNCH_C3(4, 2, 3, 2, 384, 128);
+        else if (Cout % 128 == 0) LAUNCH_C3(4, 2, 3, 2, 384, 128);
+        else LAUNCH_C3(8, 1, 2, 1, 512, 32);                     // conv_out (3 -> 32 padded output channels)
 #undef LAUNCH_C3
         return aether_check_launch("conv3_gemm_bf16");
     }

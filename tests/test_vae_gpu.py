@@ -417,7 +417,8 @@ def test_groupnorm_apply_with_fused_causal_front(cuda, hip_lib, Cc, T, spatial):
 
 @pytest.mark.parametrize("cin,cout,NB,T,H,W,kt,res", [(128, 128, 1, 2, 12, 20, 3, False), (64, 256, 2, 3, 9, 33, 3, True),
                                                       (256, 128, 1, 1, 30, 45, 3, True), (128, 256, 2, 2, 16, 24, 1, False),
-                                                      (64, 128, 3, 1, 5, 7, 1, True), (512, 512, 1, 2, 40, 61, 3, False)])
+                                                      (64, 128, 3, 1, 5, 7, 1, True), (512, 512, 1, 2, 40, 61, 3, False),
+                                                      (128, 3, 2, 3, 24, 36, 3, False), (64, 3, 1, 2, 30, 45, 3, False)])      # conv_out: 3 channels in a 512 x 32 tile
 def test_conv_tap_reuse_is_bit_identical(cuda, hip_lib, cin, cout, NB, T, H, W, kt, res):
     """conv3_kernel.hpp (one staged input tile for the three dw taps, rows enumerated over the padded plane) against the
     plain gathered kernel: same K order inside every output -> the same bits; tiles that straddle frames, batch items and

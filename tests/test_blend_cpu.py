@@ -191,3 +191,32 @@ def test_deferred_camera_algebra_matches_immediate():
 
     for a, b, what in zip(run(False), run(True), ("rgb", "disparity", "poses", "pointmaps")):
         assert np.array_equal(a, b), what
+
+
+def test_kalman_translations_match_an_independent_per_axis_filter():
+    """filterpy is absent, so the Kalman branch (U:751-844) cannot be pinned by the reference; the next best thing: F, H, Q, R and P0 of the reference's filter
+    are isotropic, so the 6-state filter decouples into three independent (position, velocity) filters.  A separately written 2-state scalar recursion
+    (textbook covariance update P = (I - K H) P instead of the Joseph form) fed with the same gaussian-pre-smoothed translations must reproduce
+    smooth_trajectory's translations."""
+    rng = np.random.default_rng(5)
+    n = 23
+    poses = np.tile(np.eye(4), (n, 1, 1))
+    poses[:, :3, 3] = np.cumsum(rng.normal(0.02, 0.05, (n, 3)), axis=0)
+    got = G.smooth_trajectory(poses.copy(), 5)[:, :3, 3]
+    pre = G.smooth_poses(poses.copy(), 5, method="gaussian")[:, :3, 3]
+    want = np.zeros_like(pre)
+    for ax in range(3):
+        z = pre[:, ax]
+        pos, vel = z[0], 0.0
+        p11, p12, p22 = 1.0, 0.0, 1.0                       # P0 = I
+        want[0, ax] = z[0]
+        for i in range(1, n):
+            pos, vel = pos + vel, vel                        # x = F x
+            p11, p12, p22 = p11 + 2 * p12 + p22 + 0.1, p12 + p22, p22 + 0.1      # P = F P F' + Q
+            s = p11 + 0.1                                    # S = H P H' + R
+            k1, k2 = p11 / s, p12 / s
+            y = z[i] - pos
+            pos, vel = pos + k1 * y, vel + k2 * y
+            p11, p12, p22 = (1 - k1) * p11, (1 - k1) * p12, p22 - k2 * p12       # P = (I - K H) P
+            want[i, ax] = pos
+    assert np.abs(got - want).max() < 1e-10

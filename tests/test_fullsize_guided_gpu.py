@@ -317,7 +317,8 @@ def test_seventeen_frame_clip_full_size(cuda, modules):
 # after 10, 5.2e-3 after 20, 7.8e-3 after 35, 1.04e-2 after 50, final 1.047e-2 / 2.76 % — against 1.354e-2 for the CPU-semantics fixture: a quarter of what round 4
 # reported as the 50-step drift was the oracle's own CPU artefact.  Decoded clips: 4 steps rgb 39.2 dB / disparity 2.16e-2, 50 steps rgb 38.5 dB / disparity 2.11e-2
 # (CPU-semantics fixtures: 39.1 / 2.19e-2 and 36.9 / 2.58e-2).  Bounds ~1.3 x measured (PSNR: - 2 dB).
-RECON_DEVICE_BOUNDS = {4: dict(lat_rel=1.38e-2, lat_linf=0.020, psnr=37.2, disp_rel=2.8e-2), 50: dict(lat_rel=1.36e-2, lat_linf=0.036, psnr=36.5, disp_rel=2.75e-2)}
+# `ref_rel`: the bf16 ORACLE's own final-latent distance on the same trajectories (profiles/r05_bf16_oracle_calibration_recon.json: 1.342e-2 after 4 steps, 1.135e-2 after 50): the native path must not be above it.
+RECON_DEVICE_BOUNDS = {4: dict(lat_rel=1.38e-2, lat_linf=0.020, ref_rel=1.342e-2, psnr=37.2, disp_rel=2.8e-2), 50: dict(lat_rel=1.36e-2, lat_linf=0.036, ref_rel=1.135e-2, psnr=36.5, disp_rel=2.75e-2)}
 
 
 @pytest.mark.parametrize("steps", [4, 50])
@@ -346,6 +347,6 @@ def test_reconstruction_against_device_oracle(cuda, modules, steps):
     assert np.isfinite(out.rgb).all() and np.isfinite(out.disparity).all()
     bd = RECON_DEVICE_BOUNDS[steps]
     if bd is not None:
-        assert max(errs) <= bd["lat_rel"] and fin["rel_l2"] <= bd["lat_rel"] and fin["linf_rel"] <= bd["lat_linf"], (errs, fin)
+        assert max(errs) <= bd["lat_rel"] and fin["rel_l2"] <= bd["ref_rel"] and fin["linf_rel"] <= bd["lat_linf"], (errs, fin)
         if p_rgb is not None and bd.get("psnr") is not None:
             assert p_rgb >= bd["psnr"] and m_disp["rel_l2"] <= bd["disp_rel"], (p_rgb, m_disp)

@@ -228,7 +228,7 @@ def stage_calib(dit32, runs):
                                "trajectories on the named inputs, dynamic CFG, identical noise and condition latents", **res}, f, indent=1)
 
 
-def stage_recon(dit, steps, name, keep):
+def stage_recon(dit, steps, name, keep, compute_dtype=torch.float32):
     """The RECONSTRUCTION call of tools/make_fullsize_golden.py (stage_clip / stage_traj: same clip, seed CLIP_SEED, same posterior sample — the sampled
     video latents come from tests/golden/fullsize_clip_condition.npz, written by the fp32 CPU oracle VAE in the build container) with the fp32 oracle
     transformer on the device: B = 1, no guidance, `steps` steps.  Same oracle code as the CPU fixtures; the difference is where torch executes the
@@ -255,18 +255,44 @@ def stage_recon(dit, steps, name, keep):
             step_lat[i] = fc.bf16_bits(latents[:, :, :, ::6, ::6].cpu())
 
     trace["on_step"] = on_step
+
+    class AsBf16:                                                      # the reference dtype: bf16 in, bf16 weights, bf16 out (see run_guided)
+        def __call__(self, hidden_states, encoder_hidden_states, timestep, **kw):
+            return (dit(hidden_states=hidden_states.to(torch.bfloat16), encoder_hidden_states=encoder_hidden_states.to(torch.bfloat16), timestep=timestep, **kw)[0],)
+
     t0 = time.perf_counter()
-    sample("reconstruction", dit, vae, CogVideoXDPMScheduler(), fc.prompt_embeds(), video=v, height=fc.HEIGHT, width=fc.WIDTH, num_frames=fc.FRAMES,
+    sample("reconstruction", dit if compute_dtype == torch.float32 else AsBf16(), vae, CogVideoXDPMScheduler(), fc.prompt_embeds(), video=v, height=fc.HEIGHT, width=fc.WIDTH, num_frames=fc.FRAMES,
            num_inference_steps=steps, generator=torch.Generator().manual_seed(fc.CLIP_SEED), rope=_rope(), compute_dtype=torch.float32, trace=trace,
            device=DEV, vae_device="cpu", video_latents=video_latents)
     total = time.perf_counter() - t0
     kept = sorted(step_lat)
+    if name is None:                                                   # calibration run: hand the trajectory back, write nothing
+        return dict(step_lat=step_lat, final_latents=trace["final_latents"].cpu(), seconds_total=total)
     meta = dict(task="reconstruction", steps=steps, kept_steps=kept, clip_seed=fc.CLIP_SEED, dit_seed=fc.DIT_SEED, vae_seed=fc.VAE_SEED, step_seconds=times,
                 seconds_total=total, torch=torch.__version__, decoded=False,
                 generated_on=f"fp32 oracle transformer with torch on {_devname()} (tools/make_fullsize_golden_gpu.py); video latents from the fp32 CPU oracle VAE")
     np.savez_compressed(os.path.join(OUT, name), step_latents_s6=np.stack([step_lat[k] for k in kept]), final_latents_bits=fc.bf16_bits(trace["final_latents"].cpu()),
                         meta=json.dumps(meta))
     log(f"reconstruction, {steps} steps: {total:.0f} s on the device; wrote gpurun_out/fixtures/{name}")
+
+
+def stage_calib_recon(dit32, step_counts):
+    """The reconstruction trajectories with the oracle transformer in the REFERENCE dtype (bf16) against the committed device-semantics fixtures
+    (tests/golden/fullsize_recon<n>_device.npz): what bf16 itself costs along the headline configuration's 50 steps."""
+    dit = dit32 if next(dit32.parameters()).dtype == torch.bfloat16 else dit32.to(torch.bfloat16)
+    res = {}
+    for n in step_counts:
+        z = np.load(os.path.join(fc.GOLDEN_DIR, f"fullsize_recon{n}_device.npz"))
+        kept = list(json.loads(str(z["meta"]))["kept_steps"])
+        tr = stage_recon(dit, n, None, set(kept), torch.bfloat16)
+        per = {int(i): fc.metrics(fc.from_bf16_bits(tr["step_lat"][i]).float(), fc.from_bf16_bits(z["step_latents_s6"][k]).float()) for k, i in enumerate(kept)}
+        fin = fc.metrics(tr["final_latents"].float(), fc.from_bf16_bits(z["final_latents_bits"]).float())
+        res[f"reconstruction_{n}_steps"] = {"seconds_device": tr["seconds_total"], "per_step_rel_l2": {k: v["rel_l2"] for k, v in per.items()}, "final_latents": fin}
+        log(f"calib_recon {n}: bf16 oracle vs fp32 device-semantics fixture: {json.dumps(fin)}")
+        np.savez_compressed(os.path.join(OUT, f"bf16_oracle_recon{n}_final_latents.npz"), final_latents_bits=fc.bf16_bits(tr["final_latents"]))
+        with open(os.path.join(OUT, "bf16_oracle_calibration_recon.json"), "w") as f:
+            json.dump({"case": "the ORACLE transformer in the reference dtype (bf16, torch's own kernels on MI355X) vs the same oracle in fp32 (device semantics), reconstruction "
+                               "trajectories of the full-size clip, identical noise and video latents", **res}, f, indent=1)
 
 
 def stage_calib_full(dit32, tasks):
@@ -315,6 +341,9 @@ def main():
             n = int(st[5:])
             keep = set(fc.HEADLINE_KEEP) if n == fc.HEADLINE_STEPS else set(range(n))
             stage_recon(dit, n, f"fullsize_recon{n}_device.npz", keep)
+            continue
+        if st == "calib_recon":                                    # converts the transformer to bf16 in place: after every fp32 stage
+            stage_calib_recon(dit, [4, 50])
             continue
         if st == "calib_full":                                     # needs the committed fixtures; converts the transformer to bf16 in place: LAST stage
             stage_calib_full(dit, ["prediction", "planning"])

@@ -27,8 +27,12 @@ def main():
                                                                              "fixtures' decoded clips (every 8th row / column)"}
     s = fc.DEC_STRIDE
     for task in tasks:
-        z = np.load(os.path.join(fc.GOLDEN_DIR, f"fullsize_{task}50.npz"))
-        lat = fc.from_bf16_bits(np.load(os.path.join(fc.ROOT, "gpurun_out", "fixtures", f"bf16_full_oracle_{task}50_final_latents.npz"))["final_latents_bits"])
+        if task.startswith("recon"):                                   # recon4 / recon50: the reconstruction trajectories under device semantics (calib_recon)
+            z = np.load(os.path.join(fc.GOLDEN_DIR, f"fullsize_{task}_device.npz"))
+            lat = fc.from_bf16_bits(np.load(os.path.join(fc.ROOT, "gpurun_out", "fixtures", f"bf16_oracle_{task}_final_latents.npz"))["final_latents_bits"])
+        else:
+            z = np.load(os.path.join(fc.GOLDEN_DIR, f"fullsize_{task}50.npz"))
+            lat = fc.from_bf16_bits(np.load(os.path.join(fc.ROOT, "gpurun_out", "fixtures", f"bf16_full_oracle_{task}50_final_latents.npz"))["final_latents_bits"])
         t0 = time.perf_counter()
 
         def dec(x):

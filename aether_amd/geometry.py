@@ -220,7 +220,8 @@ def smooth_trajectory(poses: np.ndarray, window_size: int = 5) -> np.ndarray:
     with filterpy.kalman.KalmanFilter(dim_x=6, dim_z=3), F = [[I, I], [0, I]], H = [I 0], Q = 0.1 I, R = 0.1 I, P0 = I; the
     predict / update equations below are filterpy's, Joseph-form covariance update included), and a locally weighted
     quaternion average (gaussian weights, sigma = window/4) for the rotations.
-    filterpy is not installed in the build environment: this branch is NOT covered by the golden fixtures."""
+    Pinned by tests/golden/blend_kalman.npz and blend_fullsize.npz: the reference's own smooth_trajectory run against a stand-in for the absent
+    filterpy (tools/make_blend_golden.py)."""
     from scipy.spatial.transform import Rotation as R
     N = poses.shape[0]
     F = np.eye(6)

@@ -12,6 +12,8 @@ from aether_amd import geometry as G
 from aether_amd.windows import WindowResult, blend_and_merge_window_results
 
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "blend.npz"))
+# the default `--smooth_method kalman` (D:173-179) of the reference, run against a stand-in for the absent filterpy (tools/make_blend_golden.py)
+KALMAN = np.load(os.path.join(os.path.dirname(__file__), "golden", "blend_kalman.npz"))
 H, W = (int(v) for v in GOLD["hw"])
 
 
@@ -29,16 +31,28 @@ def _windows():
 
 @pytest.mark.parametrize("tag,kw", [("plain", dict(align_pointmaps=False, smooth_camera=False)),
                                     ("aligned", dict(align_pointmaps=True, smooth_camera=False)),
-                                    ("smooth", dict(align_pointmaps=False, smooth_camera=True, smooth_method="simple"))])
+                                    ("smooth", dict(align_pointmaps=False, smooth_camera=True, smooth_method="simple")),
+                                    ("kalman", dict(align_pointmaps=False, smooth_camera=True, smooth_method="kalman")),
+                                    ("kalman_aligned", dict(align_pointmaps=True, smooth_camera=True, smooth_method="kalman"))])
 @pytest.mark.parametrize("device", [None, "cpu"])     # None: host numpy; "cpu": the torch path that runs on the GPU in scripts/demo.py
 def test_blend_matches_reference(tag, kw, device):
+    gold = KALMAN if tag.startswith("kalman") else GOLD
     rgb, disp, poses, pm = blend_and_merge_window_results(_windows(), height=H, width=W, device=device, **kw)
     assert all(isinstance(a, np.ndarray) and a.dtype == np.float64 for a in (rgb, disp, poses, pm))
     assert rgb.shape == (19, H, W, 3) and disp.shape == (19, H, W) and poses.shape == (19, 4, 4) and pm.shape == (19, H, W, 3)
     _close(rgb, GOLD["plain_rgb"], f"{tag} rgb")
-    _close(disp, GOLD[f"{tag}_disparity"], f"{tag} disparity")
-    _close(poses, GOLD[f"{tag}_poses"], f"{tag} poses")
-    _close(pm, GOLD[f"{tag}_pointmaps"], f"{tag} pointmaps")
+    _close(disp, gold[f"{tag}_disparity"], f"{tag} disparity")
+    _close(poses, gold[f"{tag}_poses"], f"{tag} poses")
+    _close(pm, gold[f"{tag}_pointmaps"], f"{tag} pointmaps")
+
+
+def test_kalman_smoothing_matches_reference():
+    """`smooth_trajectory` (U:751-844) as the reference computes it (its own source, with the published predict / update equations of
+    filterpy.kalman.KalmanFilter standing in for the absent package): a window's decoded cameras, and a noisy walk with large rotations at
+    window sizes 5 and 9."""
+    _close(G.smooth_trajectory(KALMAN["unit_in_a"].copy(), 5), KALMAN["unit_out_a"], "window cameras", 1e-10)
+    _close(G.smooth_trajectory(KALMAN["unit_in_b"].copy(), 5), KALMAN["unit_out_b"], "walk, window 5", 1e-10)
+    _close(G.smooth_trajectory(KALMAN["unit_in_b"].copy(), 9), KALMAN["unit_out_b_w9"], "walk, window 9", 1e-10)
 
 
 def test_rgb_only_blend_agrees():
@@ -79,8 +93,8 @@ def test_geometry_units_match_reference():
 
 
 def test_kalman_branch_runs_and_is_smooth():
-    """filterpy is absent from the build image, so the Kalman branch (U:751-844) cannot be pinned; check that it runs, keeps
-    valid rotations and does not move a smooth trajectory far."""
+    """Properties of the Kalman branch (U:751-844; its values are pinned by test_kalman_smoothing_matches_reference): keeps valid rotations and
+    does not move a smooth trajectory far."""
     p, _, _ = G.raymap_to_poses(GOLD["raymap_1"].copy(), ray_o_scale_inv=0.1)
     s = G.smooth_trajectory(p.copy(), 5)
     assert s.shape == p.shape and np.isfinite(s).all()
@@ -113,12 +127,14 @@ def test_camera_pose_to_raymap_matches_reference_and_round_trips():
 def test_blend_on_the_gpu_matches_reference():
     """The device merge on the MI355X (float64 torch kernels) against the reference's outputs."""
     import torch
-    for tag, kw in (("plain", dict(smooth_camera=False)), ("smooth", dict(smooth_camera=True, smooth_method="simple"))):
+    for tag, kw in (("plain", dict(smooth_camera=False)), ("smooth", dict(smooth_camera=True, smooth_method="simple")),
+                    ("kalman", dict(smooth_camera=True, smooth_method="kalman"))):
+        gold = KALMAN if tag == "kalman" else GOLD
         rgb, disp, poses, pm = blend_and_merge_window_results(_windows(), height=H, width=W, device=torch.device("cuda:0"), **kw)
         _close(rgb, GOLD["plain_rgb"], f"{tag} rgb")
-        _close(disp, GOLD[f"{tag}_disparity"], f"{tag} disparity")
-        _close(poses, GOLD[f"{tag}_poses"], f"{tag} poses")
-        _close(pm, GOLD[f"{tag}_pointmaps"], f"{tag} pointmaps")
+        _close(disp, gold[f"{tag}_disparity"], f"{tag} disparity")
+        _close(poses, gold[f"{tag}_poses"], f"{tag} poses")
+        _close(pm, gold[f"{tag}_pointmaps"], f"{tag} pointmaps")
 
 
 def test_device_merge_accepts_gathered_tensors():
@@ -194,7 +210,7 @@ def test_deferred_camera_algebra_matches_immediate():
 
 
 def test_kalman_translations_match_an_independent_per_axis_filter():
-    """filterpy is absent, so the Kalman branch (U:751-844) cannot be pinned by the reference; the next best thing: F, H, Q, R and P0 of the reference's filter
+    """Independent of the stand-in filter behind blend_kalman.npz: F, H, Q, R and P0 of the reference's filter
     are isotropic, so the 6-state filter decouples into three independent (position, velocity) filters.  A separately written 2-state scalar recursion
     (textbook covariance update P = (I - K H) P instead of the Joseph form) fed with the same gaussian-pre-smoothed translations must reproduce
     smooth_trajectory's translations."""

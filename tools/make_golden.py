@@ -307,6 +307,22 @@ def pipeline_parts():
     return dit, vae, CogVideoXDPMScheduler, prompt
 
 
+def platform_probe(vae=None) -> str:
+    """What `torch_version` / `cpu_capability` do not say: which bf16 CPU kernels oneDNN picks on THIS host (two "AVX512" hosts of the build pool
+    gave different bits for the same bf16 VAE encode).  sha256 of the small bf16 oracle VAE's encode -> decode of the fixture video: the
+    fixture's bit-exact assertions apply only where this matches, the bf16 tolerances elsewhere."""
+    import hashlib
+    import torch
+    if vae is None:
+        vae = pipeline_parts()[1]
+    video, _ = pipeline_inputs()
+    x = torch.from_numpy(video[:9]).permute(3, 0, 1, 2)[None].to(torch.bfloat16) * 2 - 1
+    with torch.no_grad():
+        z = vae.encode(x).latent_dist.mean
+        y = vae.decode(z).sample
+    return hashlib.sha256(z.float().numpy().tobytes() + y.float().numpy().tobytes()).hexdigest()[:16]
+
+
 def pipeline_inputs():
     g = np.random.default_rng(3)
     yy, xx = np.mgrid[0:PIPE_H, 0:PIPE_W]
@@ -367,7 +383,8 @@ def run_pipeline_case(pipe, kw, record):
 def make_pipeline_golden():
     import torch
     ref, StubBase = import_reference_pipeline()
-    out = {"torch_version": np.array(torch.__version__), "cpu_capability": np.array(torch.backends.cpu.get_cpu_capability())}
+    out = {"torch_version": np.array(torch.__version__), "cpu_capability": np.array(torch.backends.cpu.get_cpu_capability()),
+           "platform_probe": np.array(platform_probe())}
 
     # --- module-level functions of the reference (P:25-163) ------------------------------------------------------------
     rope_cases = [((30, 45), 45, 30, 11, 1.0), ((30, 45), 45, 30, 11, 0.5), ((30, 45), 45, 30, 5, 1.5), ((6, 15), 15, 6, 5, 12 / 8),

@@ -495,6 +495,10 @@ class AetherV1PipelineCogVideoX(_PipelineBase):
         self._interrupt = False
         batch_size = 1
         device = self._execution_device
+        # one VAE workspace for every task at this geometry (clip encode, one-frame image / goal encode, latent-clip decode): reserved before the
+        # first encode so that neither this call nor a later call of another task re-allocates it (and drops captured hipGraphs)
+        if hasattr(self.vae, "reserve_workspace"):
+            self.vae.reserve_workspace(num_frames, height, width)
 
         prompt_embeds = self.empty_prompt_embeds.to(device)
         num_inference_steps = num_inference_steps or self._default_num_inference_steps[task]

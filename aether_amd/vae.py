@@ -288,6 +288,35 @@ class AetherVAE:
         except Exception:
             pass
 
+    def reserve_workspace(self, num_frames: int, height: int, width: int) -> int:
+        """Size the launch-plan workspace ONCE for everything a pipeline call of this geometry runs (P:557-618 then P:931,936 inside one `__call__`):
+        the encode of the `num_frames` clip (reconstruction), the encode of ONE frame (the image / goal of prediction and planning) and the decode of
+        the resulting latent clip — the maximum of the three, so that no later call of any task re-allocates and drops captured hipGraphs.
+        A no-op when the workspace already covers it.  Returns the workspace size in bytes."""
+        if not (self.use_c_plan and self._loaded):
+            return 0
+        down = 2 ** (len(self.config.block_out_channels) - 1)
+        ct = self.config.temporal_compression_ratio
+        zT, zH, zW = (num_frames - 1) // ct + 1, height // down, width // down
+        need = 0
+        for decode, (T, H, W) in ((0, (num_frames, height, width)), (0, (1, height, width)), (1, (zT, zH, zW))):
+            n = self._lib.aether_vae_workspace_bytes(self._handle, decode, T, H, W, int(self.use_tiling))
+            if n == 0:
+                raise RuntimeError("aether_vae_workspace_bytes: " + self._lib.aether_last_error().decode())
+            need = max(need, int(n))
+        need += 8 << 20                        # the tap-offset tables of the other direction / geometries (see _run_c_plan)
+        if self._workspace is not None and self._workspace.numel() >= need:
+            return self._workspace.numel()
+        if self._graphs:
+            import warnings
+            warnings.warn(f"AetherVAE: workspace grows to {need / 2**30:.1f} GiB; {len(self._graphs)} captured hipGraph(s) dropped", stacklevel=2)
+        self._workspace = None
+        self._graphs.clear()
+        torch.cuda.empty_cache()
+        self._ws_bytes = max(need, 0 if self._ws_bytes is None else self._ws_bytes)
+        self._workspace = torch.empty(self._ws_bytes, dtype=torch.uint8, device=self.device)
+        return self._ws_bytes
+
     def _run_c_plan(self, x: torch.Tensor, decode: bool) -> torch.Tensor:
         """x [1, C, T, H, W] bf16 on the device -> [1, C_out, T_out, H_out, W_out] through ONE C call (replayed from a hipGraph
         when `use_graphs`: the call only enqueues — ~4 700 kernels per decode — so its capture is valid for a fixed geometry,

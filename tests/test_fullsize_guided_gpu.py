@@ -65,9 +65,9 @@ def _guided_inputs(task):
 GUIDED_BOUNDS = {
     # the B = 2 forward must stay within the bf16 ORACLE's own distance to the fixture (profiles/r04_bf16_oracle_calibration_guided.json:
     # prediction 1.84e-2 / 2.83 %, planning 1.84e-2 / 2.40 %): no worse than the reference dtype
-    "prediction": dict(post_rel=1.5e-2, fwd_rel=1.84e-2, fwd_linf=0.0283, lat_rel=2.9e-2, lat_linf=0.04, psnr=30.8, disp_rel=5.9e-2),
+    "prediction": dict(post_rel=1.45e-2, fwd_rel=1.84e-2, fwd_linf=0.0283, lat_rel=2.86e-2, lat_linf=0.039, psnr=30.8, disp_rel=5.85e-2),
     # planning: posteriors 1.07e-2 / 1.11e-2; B = 2 forward 1.38e-2 / 1.96 %; 2 guided steps: latents 2.46e-2 / 4.00 %, rgb 32.3 dB, disparity 4.4e-2
-    "planning": dict(post_rel=1.5e-2, fwd_rel=1.84e-2, fwd_linf=0.024, lat_rel=3.2e-2, lat_linf=0.052, psnr=30.0, disp_rel=5.7e-2),
+    "planning": dict(post_rel=1.44e-2, fwd_rel=1.79e-2, fwd_linf=0.024, lat_rel=3.2e-2, lat_linf=0.052, psnr=30.0, disp_rel=5.7e-2),
 }
 
 
@@ -134,10 +134,20 @@ def test_guided_call_two_steps(cuda, modules, task):
     bd = GUIDED_BOUNDS[task]
     image, goal, raymap = _guided_inputs(task)
     pipe = _pipeline(dit, vae)
+    # ONE VAE workspace per pipeline geometry (AetherVAE.reserve_workspace, called at the top of `__call__`): a guided call — 1-frame image / goal
+    # encodes, then two 11-frame decodes — must neither re-allocate it nor drop a captured hipGraph, whatever ran before (round 5 regrew 18 GB here)
+    import warnings
+    vae.reserve_workspace(fc.FRAMES, fc.HEIGHT, fc.WIDTH)
+    ws_ptr, graphs_before = vae._workspace.data_ptr(), set(vae._graphs)
     t0 = time.perf_counter()
-    out = pipe(task=task, image=image, goal=goal, raymap=raymap, height=fc.HEIGHT, width=fc.WIDTH, num_frames=fc.FRAMES, fps=12,
-               num_inference_steps=fc.GUIDED_STEPS, generator=torch.Generator().manual_seed(fc.GUIDED_SEED))
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        out = pipe(task=task, image=image, goal=goal, raymap=raymap, height=fc.HEIGHT, width=fc.WIDTH, num_frames=fc.FRAMES, fps=12,
+                   num_inference_steps=fc.GUIDED_STEPS, generator=torch.Generator().manual_seed(fc.GUIDED_SEED))
     dt = time.perf_counter() - t0
+    assert not [w for w in caught if "workspace grows" in str(w.message)], [str(w.message) for w in caught]
+    assert vae._workspace.data_ptr() == ws_ptr and graphs_before <= set(vae._graphs), "the VAE workspace was re-allocated inside a guided call"
+    assert isinstance(vae._graphs.get((True, fc.LAT_F, fc.LAT_H, fc.LAT_W, True)), tuple), "the second decode of the call should have been captured as a hipGraph"
     lat, ref_lat = pipe._final_latents.cpu().float(), fc.from_bf16_bits(z["final_latents_bits"]).float()
     ml = fc.metrics(lat, ref_lat)
     s = fc.DEC_STRIDE
@@ -150,25 +160,6 @@ def test_guided_call_two_steps(cuda, modules, task):
     assert out.rgb.shape == (fc.FRAMES, fc.HEIGHT, fc.WIDTH, 3) and np.isfinite(out.rgb).all() and np.isfinite(out.disparity).all()
     assert ml["rel_l2"] <= bd["lat_rel"] and ml["linf_rel"] <= bd["lat_linf"], ml
     assert p_rgb >= bd["psnr"] and m_disp["rel_l2"] <= bd["disp_rel"], (p_rgb, m_disp)
-
-
-def test_reconstruction_trajectory_ten_steps(cuda, modules):
-    """Drift against the fp32 oracle along a 10-step reconstruction trajectory (same clip and seed as the 4-step fixture): rel-L2 of the
-    latents after every step.  What DESIGN §2 states for the 50-step configs is the growth measured here."""
-    dit, vae = modules
-    z, meta = _load("fullsize_traj.npz")
-    pipe = _pipeline(dit, vae)
-    ref_steps = z["step_latents_s6"]
-
-    _, rec = _trajectory(pipe, fc.TRAJ_STEPS)
-    per_step = [rec[i] for i in range(fc.TRAJ_STEPS)]
-    assert len(per_step) == fc.TRAJ_STEPS == ref_steps.shape[0]
-    errs = [fc.metrics(per_step[i].to(torch.bfloat16).float(), fc.from_bf16_bits(ref_steps[i]).float())["rel_l2"] for i in range(fc.TRAJ_STEPS)]
-    fin = fc.metrics(pipe._final_latents.cpu().float()[..., ::2, ::2], fc.from_bf16_bits(z["final_latents_s2_bits"]).float())
-    print("\n[fullsize] 10-step reconstruction trajectory, latents rel-L2 vs fp32 oracle after each step: " + " ".join(f"{e:.2e}" for e in errs)
-          + f"; final (every 2nd pixel): rel-L2 {fin['rel_l2']:.3e}  L-inf {100 * fin['linf_rel']:.2f} % of max")
-    # measured: 1.8e-3 after step 0, growing like the square root of the step count to 9.5e-3 after step 9; final 9.49e-3 / 1.85 % (bounds ~1.3 x)
-    assert max(errs) <= 1.25e-2 and fin["rel_l2"] <= 1.25e-2 and fin["linf_rel"] <= 0.025, (errs, fin)
 
 
 def _trajectory(pipe, steps, keep=None, task="reconstruction", seed=None, scales=None, **inputs):
@@ -205,31 +196,6 @@ def _trajectory(pipe, steps, keep=None, task="reconstruction", seed=None, scales
     out = pipe(task=task, height=fc.HEIGHT, width=fc.WIDTH, num_frames=fc.FRAMES, fps=12, num_inference_steps=steps,
                generator=torch.Generator().manual_seed(fc.CLIP_SEED if seed is None else seed), **inputs)
     return out, rec
-
-
-def test_headline_reconstruction_fifty_steps(cuda, modules):
-    """BASELINE configs[1] ITSELF — "4D reconstruction, 41x480x720, 50 steps" — against the fp32 oracle's whole 50-step call (5.6 h of CPU
-    offline, tools/make_fullsize_golden.py traj50): latents along the trajectory, final latents (L-inf / rel-L2), decoded rgb PSNR and disparity."""
-    path = os.path.join(fc.GOLDEN_DIR, "fullsize_traj50.npz")
-    if not os.path.exists(path):
-        pytest.skip("tests/golden/fullsize_traj50.npz not generated yet (tools/make_fullsize_golden.py traj50: ~6 h of CPU)")
-    dit, vae = modules
-    z, meta = _load("fullsize_traj50.npz")
-    pipe = _pipeline(dit, vae)
-    kept = list(meta["kept_steps"])
-    out, rec = _trajectory(pipe, fc.HEADLINE_STEPS, set(kept))
-    errs = [fc.metrics(rec[i].to(torch.bfloat16).float(), fc.from_bf16_bits(z["step_latents_s6"][k]).float())["rel_l2"] for k, i in enumerate(kept)]
-    fin = fc.metrics(pipe._final_latents.cpu().float()[..., ::2, ::2], fc.from_bf16_bits(z["final_latents_s2_bits"]).float())
-    s = fc.DEC_STRIDE
-    p_rgb = fc.psnr(torch.from_numpy(out.rgb)[:, ::s, ::s], torch.from_numpy(z["rgb_s8"].astype(np.float32)))
-    m_disp = fc.metrics(torch.from_numpy(out.disparity)[:, ::s, ::s], torch.from_numpy(z["disparity_s8"].astype(np.float32)))
-    print("\n[fullsize] HEADLINE config, 50-step reconstruction: latents rel-L2 vs fp32 oracle after steps " + ", ".join(f"{i}: {e:.2e}" for i, e in zip(kept, errs))
-          + f"; final (every 2nd pixel): rel-L2 {fin['rel_l2']:.3e}  L-inf {100 * fin['linf_rel']:.2f} % of max; rgb PSNR {p_rgb:.1f} dB; disparity rel-L2 {m_disp['rel_l2']:.3e}"
-          + f" ({meta['seconds_cpu_total']:.0f} s of CPU offline)")
-    # measured on MI355X: 7.4e-4 after step 0, 5.9e-3 after 10 steps, 9.2e-3 after 20, 1.03e-2 after 35, 1.35e-2 after 50; final 1.354e-2 / 2.74 %;
-    # rgb 36.9 dB; disparity 2.58e-2 (bounds ~1.3 x)
-    assert np.isfinite(out.rgb).all() and max(errs) <= 1.8e-2 and fin["rel_l2"] <= 1.8e-2 and fin["linf_rel"] <= 0.036, (errs, fin)
-    assert p_rgb >= 34.6 and m_disp["rel_l2"] <= 3.4e-2, (p_rgb, m_disp)
 
 
 # ---- BASELINE configs[2] / configs[3] at the step count BASELINE QUOTES: 50 guided steps, dynamic CFG on the n = 50 schedule ----------------------
@@ -279,7 +245,10 @@ def test_guided_call_fifty_steps(cuda, modules, task):
         p_rgb = fc.psnr(torch.from_numpy(out.rgb)[:, ::s, ::s], torch.from_numpy(z["rgb_s8"].astype(np.float32)))
         m_disp = fc.metrics(torch.from_numpy(out.disparity)[:, ::s, ::s], torch.from_numpy(z["disparity_s8"].astype(np.float32)))
         msg += f"; rgb PSNR {p_rgb:.1f} dB; disparity rel-L2 {m_disp['rel_l2']:.3e}"
-    print(msg)
+    from einops import rearrange                  # the raymap output is the camera channels of the final latents, un-folded (P:942-945)
+    ref_ray = rearrange(fc.from_bf16_bits(z["final_latents_bits"]).float()[:, :, 32:], "b t (n c) h w -> b (n t) c h w", n=4)[0, -fc.FRAMES:]
+    m_ray = fc.metrics(torch.from_numpy(out.raymap), ref_ray)
+    print(msg + f"; raymap rel-L2 {m_ray['rel_l2']:.3e}")
     assert out.rgb.shape == (fc.FRAMES, fc.HEIGHT, fc.WIDTH, 3) and np.isfinite(out.rgb).all() and np.isfinite(out.disparity).all()
     assert max(errs) <= bd["lat_rel"] and fin["rel_l2"] <= bd["ref_rel"] and fin["linf_rel"] <= bd["ref_linf"], (errs, fin)
     if p_rgb is not None and bd["psnr"] is not None:
@@ -305,7 +274,8 @@ def test_seventeen_frame_clip_full_size(cuda, modules):
 
 
 # ---- the reconstruction trajectories under DEVICE semantics ------------------------------------------------------------------------------------------
-# The CPU-generated trajectory fixtures above (fullsize_clip / _traj / _traj50 / _prediction / _planning) contain an artefact of torch-CPU: in
+# These are the PRIMARY reconstruction fixtures.  The CPU-generated trajectory fixtures of rounds 2-4 (fullsize_clip's final latents, _traj, _traj50; the 2-step
+# _prediction / _planning above) contain an artefact of torch-CPU: in
 # `m1 * sample` and `m_noise * noise` (bf16 tensor times python / 0-dim scalar, diffusers' DPM update) the CPU kernels round the SCALAR to bf16 before the
 # multiplication, a CUDA / HIP device keeps it in fp32.  The reference runs on the device (D:218), the native `aether_dpm_step` is bit-identical to the
 # device op sequence — so every step of a CPU-oracle trajectory carries a perturbation of up to 2^-9 on two coefficients that neither the reference nor the
@@ -318,7 +288,11 @@ def test_seventeen_frame_clip_full_size(cuda, modules):
 # reported as the 50-step drift was the oracle's own CPU artefact.  Decoded clips: 4 steps rgb 39.2 dB / disparity 2.16e-2, 50 steps rgb 38.5 dB / disparity 2.11e-2
 # (CPU-semantics fixtures: 39.1 / 2.19e-2 and 36.9 / 2.58e-2).  Bounds ~1.3 x measured (PSNR: - 2 dB).
 # `ref_rel`: the bf16 ORACLE's own final-latent distance on the same trajectories (profiles/r05_bf16_oracle_calibration_recon.json: 1.342e-2 after 4 steps, 1.135e-2 after 50): the native path must not be above it.
-RECON_DEVICE_BOUNDS = {4: dict(lat_rel=1.38e-2, lat_linf=0.020, ref_rel=1.342e-2, psnr=37.2, disp_rel=2.8e-2), 50: dict(lat_rel=1.36e-2, lat_linf=0.036, ref_rel=1.135e-2, psnr=36.5, disp_rel=2.75e-2)}
+# `fin_rel` = the smaller of that and 1.3 x measured; the raymap output (camera channels of the final latents, P:942-945): 9.6e-3 measured after 4 steps.
+# The 10- and 50-step CPU-semantics fixtures (fullsize_traj / _traj50) and the tests that asserted against them were retired in round 6: their bounds had to sit
+# 30 % above a distance of which a quarter was the fixture's own artefact.
+RECON_DEVICE_BOUNDS = {4: dict(lat_rel=1.38e-2, lat_linf=0.0199, fin_rel=1.32e-2, psnr=37.2, disp_rel=2.8e-2, ray_rel=1.25e-2),
+                       50: dict(lat_rel=1.36e-2, lat_linf=0.036, fin_rel=1.135e-2, psnr=36.5, disp_rel=2.75e-2, ray_rel=1.4e-2)}
 
 
 @pytest.mark.parametrize("steps", [4, 50])
@@ -343,10 +317,14 @@ def test_reconstruction_against_device_oracle(cuda, modules, steps):
         p_rgb = fc.psnr(torch.from_numpy(out.rgb)[:, ::s, ::s], torch.from_numpy(z["rgb_s8"].astype(np.float32)))
         m_disp = fc.metrics(torch.from_numpy(out.disparity)[:, ::s, ::s], torch.from_numpy(z["disparity_s8"].astype(np.float32)))
         msg += f"; rgb PSNR {p_rgb:.1f} dB; disparity rel-L2 {m_disp['rel_l2']:.3e}"
-    print(msg)
+    from einops import rearrange                  # the raymap output is the camera channels of the final latents, un-folded (P:942-945)
+    ref_ray = rearrange(fc.from_bf16_bits(z["final_latents_bits"]).float()[:, :, 32:], "b t (n c) h w -> b (n t) c h w", n=4)[0, -fc.FRAMES:]
+    m_ray = fc.metrics(torch.from_numpy(out.raymap), ref_ray)
+    print(msg + f"; raymap rel-L2 {m_ray['rel_l2']:.3e}")
     assert np.isfinite(out.rgb).all() and np.isfinite(out.disparity).all()
     bd = RECON_DEVICE_BOUNDS[steps]
     if bd is not None:
-        assert max(errs) <= bd["lat_rel"] and fin["rel_l2"] <= bd["ref_rel"] and fin["linf_rel"] <= bd["lat_linf"], (errs, fin)
+        assert max(errs) <= bd["lat_rel"] and fin["rel_l2"] <= bd["fin_rel"] and fin["linf_rel"] <= bd["lat_linf"], (errs, fin)
+        assert out.raymap.shape == (fc.FRAMES, 6, fc.LAT_H, fc.LAT_W) and m_ray["rel_l2"] <= bd["ray_rel"], m_ray
         if p_rgb is not None and bd.get("psnr") is not None:
             assert p_rgb >= bd["psnr"] and m_disp["rel_l2"] <= bd["disp_rel"], (p_rgb, m_disp)

@@ -103,6 +103,28 @@ def clip_video() -> np.ndarray:
     return np.clip(v, 0.0, 1.0).astype(np.float32)
 
 
+WINDOWS3_STARTS = (0, 24, 31)               # 72 frames: overlaps 17 AND 34, the two overlap lengths of get_window_starts(192, 41, 24) = [0, ..., 144, 151]
+WINDOWS3_TOTAL = WINDOWS3_STARTS[-1] + FRAMES if not os.environ.get("AETHER_FULLSIZE_DRYRUN") else None
+WINDOWS3_STEPS = 4
+
+
+def windows3_starts():
+    """Starts of the three-window case at the current geometry (dry run, 17-frame windows: [0, 10, 13] — overlaps 7 and 14)."""
+    return list(WINDOWS3_STARTS) if FRAMES == 41 else [0, 10, 13]
+
+
+def long_video(total: int) -> np.ndarray:
+    """[total, H, W, 3] float32 in [0, 1]: the moving sinusoid field of `clip_video`, frame by frame (every frame draws its own noise from its own
+    generator, so the first frames do not depend on `total`)."""
+    yy, xx = np.mgrid[0:HEIGHT, 0:WIDTH].astype(np.float32)
+    out = np.empty((total, HEIGHT, WIDTH, 3), np.float32)
+    for t in range(total):
+        f = np.stack([0.5 + 0.4 * np.sin(0.02 * xx + 0.1 * t + c) * np.cos(0.015 * yy) for c in range(3)], -1)
+        f = f + 0.03 * np.random.default_rng(1000 + t).standard_normal(f.shape).astype(np.float32)
+        out[t] = np.clip(f, 0.0, 1.0)
+    return out
+
+
 def video_as_model_input(video: np.ndarray) -> torch.Tensor:
     """What `preprocess_inputs` (P:462-512) hands to the VAE for a clip that needs no crop / resize: [F, 3, H, W] in [-1, 1]."""
     return torch.from_numpy(video).permute(0, 3, 1, 2) * 2 - 1

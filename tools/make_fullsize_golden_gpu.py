@@ -5,7 +5,8 @@ to write the long guided fixtures in minutes instead of 10.5 h of host CPU per t
 
   pin           re-computes what two CPU-generated fixtures hold — tests/golden/fullsize_dit.npz (one 42-block forward) and the step-0 B = 2 noise
                 prediction + 2-step final latents of tests/golden/fullsize_prediction.npz — and reports the distance device-oracle <-> CPU-oracle
-                (fp32 round-off of a different summation order: expected ~1e-5, three orders below the bf16 distances the parity tests measure).
+                (fp32 round-off of a different summation order through 42 blocks: measured 2.1e-4 rel-L2 on the forward, profiles/r05_gpu_oracle_pin.json — fifty
+                times below the bf16 distances the parity tests measure).
                 The CPU run of the SAME 50-step call (tools/make_fullsize_golden.py prediction50, checkpointing) pins the first steps of the long
                 trajectories the same way (tools/compare_partial_fixture.py).
   prediction50  BASELINE configs[2] at the quoted step count: car.png + forward-right raymap, 50 guided steps, dynamic CFG on the n = 50 schedule
@@ -276,6 +277,80 @@ def stage_recon(dit, steps, name, keep, compute_dtype=torch.float32):
     log(f"reconstruction, {steps} steps: {total:.0f} s on the device; wrote gpurun_out/fixtures/{name}")
 
 
+def stage_windows3(dit):
+    """BASELINE configs[4] END TO END at its own geometry, oracle side: a 72-frame clip cut into three 41-frame windows with starts [0, 24, 31]
+    (overlaps 17 and 34: the two overlap lengths of the reference's [0, 24, ..., 144, 151]); every window is an independent reconstruction call
+    (D:613-631: fresh generator, same seed) of the fp32 oracle — transformer AND VAE executed by torch on this device (fp32 GEMMs / fp32 convolutions,
+    explicit fp32 attention), 4 steps (the reference default, P:257-261) — and the three outputs are merged by the host merge, which the REFERENCE's own
+    blend pins at this geometry (tests/golden/blend_fullsize.npz), with the CLI's default Kalman smoothing (D:173-179).  Stored: per-window final latents
+    (exact bf16 bits), the merged rgb / disparity / point maps on a pixel lattice, all 72 poses, the fitted disparity scales."""
+    from aether_amd import geometry as G
+    from aether_amd.scheduler import CogVideoXDPMScheduler
+    from aether_amd.windows import WindowResult, blend_and_merge_window_results
+    from oracle.pipeline import sample
+    starts = fc.windows3_starts()
+    total = starts[-1] + fc.FRAMES
+    video = fc.long_video(total)
+    vae = fc.build_oracle_vae().to(DEV)
+    t0 = time.perf_counter()
+    wins, finals, secs = [], [], []
+    for s0 in starts:
+        t1 = time.perf_counter()
+        trace = {}
+        rgb, disp, rm = sample("reconstruction", dit, vae, CogVideoXDPMScheduler(), fc.prompt_embeds(), video=fc.video_as_model_input(video[s0:s0 + fc.FRAMES]),
+                               height=fc.HEIGHT, width=fc.WIDTH, num_frames=fc.FRAMES, num_inference_steps=fc.WINDOWS3_STEPS,
+                               generator=torch.Generator().manual_seed(fc.CLIP_SEED), rope=_rope(), compute_dtype=torch.float32, trace=trace, device=DEV, vae_device=DEV)
+        _sync()
+        wins.append(WindowResult(s0, rgb.cpu().numpy(), disp.cpu().numpy(), rm.cpu().numpy()))
+        finals.append(fc.bf16_bits(trace["final_latents"].cpu()))
+        secs.append(time.perf_counter() - t1)
+        log(f"windows3: window at {s0}: {secs[-1]:.0f} s (encode + {fc.WINDOWS3_STEPS} steps + 2 decodes, fp32 oracle on the device)")
+        del trace
+    scales, real = [], G.compute_scale
+
+    def recording(*a, **k):
+        scales.append(real(*a, **k))
+        return scales[-1]
+    G.compute_scale = recording
+    try:
+        m_rgb, m_disp, m_poses, m_pm = blend_and_merge_window_results([WindowResult(w.start, w.rgb, w.disparity, w.raymap.copy()) for w in wins], height=fc.HEIGHT,
+                                                                      width=fc.WIDTH, smooth_camera=True, smooth_method="kalman")
+    finally:
+        G.compute_scale = real
+    s = fc.DEC_STRIDE
+    meta = dict(task="reconstruction, sliding windows", starts=starts, total_frames=total, steps=fc.WINDOWS3_STEPS, seed=fc.CLIP_SEED, window_seconds=secs,
+                seconds_total=time.perf_counter() - t0, torch=torch.__version__, video_sum=float(video.astype(np.float64).sum()),
+                generated_on=f"fp32 oracle transformer + fp32 oracle VAE with torch on {_devname()} (tools/make_fullsize_golden_gpu.py windows3); host merge, kalman smoothing")
+    np.savez_compressed(os.path.join(OUT, "fullsize_windows3.npz"), final_latents_bits=np.stack(finals), rgb_s8=m_rgb[:, ::s, ::s].astype(np.float16),
+                        disparity_s8=m_disp[:, ::s, ::s].astype(np.float32), pointmaps_s8=m_pm[:, ::s, ::s].astype(np.float32), poses=m_poses, scales=np.array(scales),
+                        window_raymaps=np.stack([w.raymap for w in wins]).astype(np.float32), window_disparity_s8=np.stack([w.disparity[:, ::s, ::s] for w in wins]),
+                        meta=json.dumps(meta))
+    log(f"windows3: scales {scales}; wrote gpurun_out/fixtures/fullsize_windows3.npz in {meta['seconds_total']:.0f} s")
+
+
+def stage_dit17(dit):
+    """One fp32 oracle forward at the SHORTEST clip the reference admits (17 frames -> 5 latent frames, S = 226 + 6 750), B = 1: the geometry of
+    tests/test_fullsize_guided_gpu.py::test_seventeen_frame_clip_full_size, which had no oracle."""
+    from oracle.rope import prepare_rope
+    lat_f = (17 - 1) // 4 + 1 if fc.FRAMES == 41 else 3
+    frames = (lat_f - 1) * 4 + 1
+    g = torch.Generator().manual_seed(fc.DIT_INPUT_SEED + 17)
+    hidden = torch.randn(1, lat_f, 96, fc.LAT_H, fc.LAT_W, generator=g).to(torch.bfloat16)
+    text = (torch.randn(1, fc.TEXT_LEN, fc.TEXT_DIM, generator=g) * 0.1).to(torch.bfloat16)
+    t = torch.tensor([749], dtype=torch.int64)
+    rope = prepare_rope(fc.HEIGHT, fc.WIDTH, lat_f, 12)
+    _sync()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        out = dit(hidden_states=hidden.to(DEV, torch.float32), encoder_hidden_states=text.to(DEV, torch.float32), timestep=t.to(DEV), ofs=None,
+                  image_rotary_emb=(rope[0].to(DEV), rope[1].to(DEV)), return_dict=False)[0]
+    _sync()
+    np.savez_compressed(os.path.join(OUT, "fullsize_dit17.npz"), out=out.float().cpu().numpy().astype(np.float32),
+                        meta=json.dumps(dict(frames=frames, latent_frames=lat_f, timestep=749, input_seed=fc.DIT_INPUT_SEED + 17, input_sum=float(hidden.float().sum()),
+                                             seconds=time.perf_counter() - t0, generated_on=f"fp32 oracle transformer with torch on {_devname()}")))
+    log(f"dit17: one {frames}-frame forward in {time.perf_counter() - t0:.1f} s; wrote gpurun_out/fixtures/fullsize_dit17.npz")
+
+
 def stage_calib_recon(dit32, step_counts):
     """The reconstruction trajectories with the oracle transformer in the REFERENCE dtype (bf16) against the committed device-semantics fixtures
     (tests/golden/fullsize_recon<n>_device.npz): what bf16 itself costs along the headline configuration's 50 steps."""
@@ -336,6 +411,12 @@ def main():
             stage_pin(dit)
             continue
         if st == "calib":
+            continue
+        if st == "windows3":
+            stage_windows3(dit)
+            continue
+        if st == "dit17":
+            stage_dit17(dit)
             continue
         if st.startswith("recon"):                                 # recon4 / recon10 / recon50: the reconstruction fixtures under device semantics
             n = int(st[5:])

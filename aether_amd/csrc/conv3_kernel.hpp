@@ -16,14 +16,21 @@
 //
 // LDS: two A buffers (one per (dt,dh,cb) step) + two W buffers (one per K tile).  Instantiations:
 //     <2,4,4,2>  256x256   (Cout % 256 == 0)     2*40 + 2*32 = 144 KiB
-//     <4,2,3,2>  384x128   (Cout % 128 == 0)     2*56 + 2*16 = 144 KiB
+//     <4,2,3,2>  384x128   (Cout % 128 == 0; rounds 2-5)     2*56 + 2*16 = 144 KiB
+//     <4,2,4,2,W1>  512x128  (Cout % 128 == 0; round 6)      2*72 + 1*16 = 160 KiB — every byte of a CU's LDS
 //     <8,1,2,1>  512x32    (conv_out: 3 output channels padded to 32; round 5)   2*72 + 2*4 = 152 KiB
+//
+// W1 (single W buffer): the 128-wide layers are 36 % of the VAE's time and the 384x128 tile gives a wave only 6 MFMAs per fragment
+// set (96 x 64 per wave) where the 256-wide tile has 8 (128 x 64) — but 512 x 128 with the tap-reuse A tile (512 + 64 rows, twice) leaves
+// 16 KiB for W: ONE tile.  A wave therefore pulls ALL the W fragments of a K tile into registers in its first two load slots
+// (2 x NT x 2 = 8 reads, 32 VGPRs); once the later wave group has done so (end of global slot 3 of the tile) the W buffer is dead
+// and the DMA of the next K tile's W goes into the same buffer in the third load slots; it has landed when the tile-end vmcnt(0) + barrier pass.
 #pragma once
 #include "gemm_kernel.hpp"
 
 namespace aether {
 
-template <int WM, int WN, int MT, int NT, int EPI, bool WIDE_STORE>
+template <int WM, int WN, int MT, int NT, int EPI, bool WIDE_STORE, bool W1 = false>
 __global__ __launch_bounds__(512) void conv3_gemm_kernel(GemmArgs p) {
     static_assert(WM * WN == 8, "8 wavefronts per workgroup");
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
@@ -31,8 +38,10 @@ __global__ __launch_bounds__(512) void conv3_gemm_kernel(GemmArgs p) {
     constexpr int W_ROUNDS = (BN + 63) / 64;
     constexpr int A_BUF = A_ROUNDS * 8192, W_TILE = BN * 128;
     static_assert(BM % 64 == 0 && (BN % 64 == 0 || BN == 32), "tile shape");
-    static_assert(2 * A_BUF + 2 * W_TILE <= 160 * 1024, "LDS budget");
-    __shared__ __attribute__((aligned(16))) char smem[2 * A_BUF + 2 * W_TILE];
+    constexpr int W_BUFS = W1 ? 1 : 2;
+    static_assert(2 * A_BUF + W_BUFS * W_TILE <= 160 * 1024, "LDS budget");
+    static_assert(!W1 || (BN >= 64 && A_ROUNDS % 3 == 0), "single W buffer: whole DMA rounds, three A rounds per K tile");
+    __shared__ __attribute__((aligned(16))) char smem[2 * A_BUF + W_BUFS * W_TILE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -112,10 +121,20 @@ __global__ __launch_bounds__(512) void conv3_gemm_kernel(GemmArgs p) {
     }
     drain_and_barrier();
 
-    bf16x8 wf[NT], xf[MT];
+    // W1: wf[ks][nt] holds the W fragments of ALL four k-steps of the current K tile (read in load slots 0 and 1); otherwise only wf[0] is used
+    bf16x8 wf[W1 ? 4 : 1][NT], xf[MT];
     auto load_frags = [&](const char* abase, const char* wbase, int dw, int ks) {
+        if (W1) {
+            if (ks < 2) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wf[nt] = *(const bf16x8*)(wbase + w_row_base + nt * 4096 + chunk_w[ks]);
+                for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) wf[W1 ? 2 * ks + k2 : 0][nt] = *(const bf16x8*)(wbase + w_row_base + nt * 4096 + chunk_w[2 * ks + k2]);
+            }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wf[0][nt] = *(const bf16x8*)(wbase + w_row_base + nt * 4096 + chunk_w[ks]);
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) xf[mt] = *(const bf16x8*)(abase + x_row_base[dw] + mt * 4096 + chunk_x[dw][ks]);
     };
@@ -123,13 +142,27 @@ __global__ __launch_bounds__(512) void conv3_gemm_kernel(GemmArgs p) {
     int tap_stage = __builtin_amdgcn_readfirstlane(p.tap_off[3 * min(1, ng - 1)]);
     int tap_ahead = 0;
     // DMA pieces issued during K tile (g, dw): the W tile of the next K tile, and every third A round of step g+1; split
-    // over the three early load slots.  Past the end the last tiles are re-fetched into the buffers nobody reads any more.
+    // over the three early load slots.  Past the end the last tiles are re-fetched into the buffers nobody reads any more
+    // (W1: the last W tile is re-fetched over itself — same bytes — after every wave has its fragments in registers).
     auto stage_part = [&](int g, int dw, int part) {
         const int kt_next = min(3 * g + dw + 1, nk - 1);
         const unsigned w_soff = 2u * (unsigned)(kt_next * GEMM_BK), a_soff = 2u * (unsigned)tap_stage;
         char* adst = lds_stage + ((g + 1) & 1) * A_BUF;
-        char* wdst = lds_stage + 2 * A_BUF + (kt_next & 1) * W_TILE;
-        if (3 * g + dw + 1 > nk - 1) wdst = lds_stage + 2 * A_BUF + (nk & 1) * W_TILE;     // clamped re-fetch: the idle buffer
+        char* wdst = lds_stage + 2 * A_BUF + (W1 ? 0 : (kt_next & 1) * W_TILE);
+        if (!W1 && 3 * g + dw + 1 > nk - 1) wdst = lds_stage + 2 * A_BUF + (nk & 1) * W_TILE;     // clamped re-fetch: the idle buffer
+        if (W1) {
+            // the three A rounds r = dw, dw+3, dw+6 of this K tile in load slots 0 and 1; the W rounds in load slot 2 only: the W buffer is
+            // read by the early group in global slots 0, 2 and by the late group in slots 1, 3 of the tile; slot 2 of either group comes after
+            constexpr int NA = A_ROUNDS / 3;
+#pragma unroll
+            for (int j = 0; j < NA; ++j)
+                if ((j * 2) / NA == part) bglds16(a_rsrc, a_off[dw + 3 * j], a_soff, adst + (dw + 3 * j) * 8192);
+            if (part == 2) {
+#pragma unroll
+                for (int r = 0; r < W_ROUNDS; ++r) bglds16(w_rsrc, w_off[r], w_soff, wdst + r * 8192);
+            }
+            return;
+        }
         constexpr int NA = (A_ROUNDS + 2) / 3;             // upper bound of A rounds in one K tile
         int piece = 0;
         const int n_a = (A_ROUNDS - dw + 2) / 3;           // rounds r = dw, dw+3, ...
@@ -148,13 +181,13 @@ __global__ __launch_bounds__(512) void conv3_gemm_kernel(GemmArgs p) {
             ++piece;
         }
     };
-    auto mma = [&]() {
+    auto mma = [&](int ks) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[W1 ? ks : 0][nt], xf[mt], acc[mt][nt], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
     auto slot_end = [&]() {
@@ -171,14 +204,14 @@ __global__ __launch_bounds__(512) void conv3_gemm_kernel(GemmArgs p) {
             tap_ahead = p.tap_off[3 * min(g + 2, ng - 1)];
 #pragma unroll
             for (int dw = 0; dw < 3; ++dw) {
-                const char* wbase = smem + 2 * A_BUF + ((3 * g + dw) & 1) * W_TILE;
+                const char* wbase = smem + 2 * A_BUF + (W1 ? 0 : ((3 * g + dw) & 1) * W_TILE);
 #pragma unroll
                 for (int sl = 0; sl < 4; ++sl) {
                     load_frags(abase, wbase, dw, sl);
                     if (sl < 3) stage_part(g, dw, sl);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     slot_end();
-                    mma();
+                    mma(sl);
                     if (sl == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     slot_end();
                 }
@@ -191,8 +224,8 @@ __global__ __launch_bounds__(512) void conv3_gemm_kernel(GemmArgs p) {
             tap_ahead = p.tap_off[3 * min(g + 2, ng - 1)];
 #pragma unroll
             for (int dw = 0; dw < 3; ++dw) {
-                const char* wbase = smem + 2 * A_BUF + ((3 * g + dw) & 1) * W_TILE;
-                if (g > 0 || dw > 0) mma();                        // last compute slot of the previous K tile
+                const char* wbase = smem + 2 * A_BUF + (W1 ? 0 : ((3 * g + dw) & 1) * W_TILE);
+                if (g > 0 || dw > 0) mma(3);                       // last compute slot of the previous K tile
                 slot_end();
 #pragma unroll
                 for (int sl = 0; sl < 4; ++sl) {
@@ -202,14 +235,14 @@ __global__ __launch_bounds__(512) void conv3_gemm_kernel(GemmArgs p) {
                     else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     slot_end();
                     if (sl < 3) {
-                        mma();
+                        mma(sl);
                         slot_end();
                     }
                 }
             }
             tap_stage = __builtin_amdgcn_readfirstlane(tap_ahead);
         }
-        mma();                                                     // last compute slot of the last K tile
+        mma(3);                                                    // last compute slot of the last K tile
     }
 
     // ---- epilogue: rows of the padded enumeration -> compact [NB, oT, oH, oW, Cout]; padding rows are dropped ----------------

@@ -231,9 +231,20 @@ extern "C" int aether_conv_gemm_bf16(const void* X, int NB, int iT, int iH, int 
             else { if (wide) hipLaunchKernelGGL((conv3_gemm_kernel<WM_, WN_, MT_, NT_, EPI_BIAS, true>), grid, block, 0, AE_STREAM, p);            \
                    else hipLaunchKernelGGL((conv3_gemm_kernel<WM_, WN_, MT_, NT_, EPI_BIAS, false>), grid, block, 0, AE_STREAM, p); }               \
         } while (0)
+#define LAUNCH_C3_W1(WM_, WN_, MT_, NT_, BM_, BN_)                                                                                  \
+        do {                                                                                                                        \
+            p.tiles_m = (p.M + BM_ - 1) / BM_; p.tiles_n = (Cout + BN_ - 1) / BN_; p.ntile_launch = p.tiles_m * p.tiles_n;            \
+            dim3 grid(p.ntile_launch);                                                                                              \
+            if (R) { if (wide) hipLaunchKernelGGL((conv3_gemm_kernel<WM_, WN_, MT_, NT_, EPI_BIAS_GATE_RES, true, true>), grid, block, 0, AE_STREAM, p);  \
+                     else hipLaunchKernelGGL((conv3_gemm_kernel<WM_, WN_, MT_, NT_, EPI_BIAS_GATE_RES, false, true>), grid, block, 0, AE_STREAM, p); }   \
+            else { if (wide) hipLaunchKernelGGL((conv3_gemm_kernel<WM_, WN_, MT_, NT_, EPI_BIAS, true, true>), grid, block, 0, AE_STREAM, p);            \
+                   else hipLaunchKernelGGL((conv3_gemm_kernel<WM_, WN_, MT_, NT_, EPI_BIAS, false, true>), grid, block, 0, AE_STREAM, p); }               \
+        } while (0)
+        static const bool tile384 = getenv("AETHER_CONV3_384") != nullptr;   // A/B only: the 384x128 tile of rounds 2-5
         if (Cout % 256 == 0) LAUNCH_C3(2, 4, 4, 2, 256, 256);
-        else if (Cout % 128 == 0) LAUNCH_C3(4, 2, 3, 2, 384, 128);
+        else if (Cout % 128 == 0) { if (tile384) LAUNCH_C3(4, 2, 3, 2, 384, 128); else LAUNCH_C3_W1(4, 2, 4, 2, 512, 128); }
         else LAUNCH_C3(8, 1, 2, 1, 512, 32);                     // conv_out (3 -> 32 padded output channels)
+#undef LAUNCH_C3_W1
 #undef LAUNCH_C3
         return aether_check_launch("conv3_gemm_bf16");
     }

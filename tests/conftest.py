@@ -60,5 +60,8 @@ def fullsize_modules(cuda, hip_lib):
     vae = AetherVAE(dict(fc.VAE_KW), device=cuda).load_state_dict(fc.bf16_state_dict(fc.build_oracle_vae()))
     vae.enable_tiling()
     vae.enable_slicing()
+    # what a pipeline call does first (AetherV1PipelineCogVideoX.__call__ -> AetherVAE.reserve_workspace): one workspace for every task at this geometry,
+    # so that no test — whichever runs first, pipeline call or bare vae.encode / decode — re-allocates it or drops a captured hipGraph
+    vae.reserve_workspace(fc.FRAMES, fc.HEIGHT, fc.WIDTH)
     print(f"\n[fullsize] {cfg.num_layers}-block seeded weights built on the host and packed on the device in {time.perf_counter() - t0:.0f} s")
     return dit, vae

@@ -180,3 +180,55 @@ def test_gloo_round_wise_gather_and_incremental_merge(tmp_path, world):
     for k, ref in (("rgb", "plain_rgb"), ("disparity", "plain_disparity"), ("poses", "plain_poses"), ("pointmaps", "plain_pointmaps")):
         err = np.abs(got[k] - gold[ref]).max() / np.abs(gold[ref]).max()
         assert err < 1e-5, (k, err)
+
+
+_EIGHT_WORKER = textwrap.dedent('''
+    import os, sys
+    import numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, %(root)r)
+    from types import SimpleNamespace
+    from aether_amd import geometry as G
+    from aether_amd.windows import blend_and_merge_window_results, get_window_starts, run_windows, run_windows_merged
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist.init_process_group("gloo")
+    F, H, W, total = 9, 16, 24, 42
+    starts = get_window_starts(total, F, 5)                      # [0, 5, ..., 30, 33]: 8 windows, overlaps 4 and (tail) 6 — the shape of [0, 24, ..., 144, 151]
+    assert len(starts) == 8 and starts[-2:] == [30, 33]
+    t = np.linspace(0, 1, total)
+    K = np.array([[20.0, 0, W / 2], [0, 20.0, H / 2], [0, 0, 1.0]])
+    yy, xx = np.mgrid[0:H, 0:W]
+    def call(s):                                                 # a deterministic function of the start only: every rank can make every window
+        k = starts.index(s)
+        pose = np.tile(np.eye(4), (F, 1, 1))
+        a = 0.4 * (t[s:s + F] - t[s])
+        pose[:, 0, 0], pose[:, 0, 2], pose[:, 2, 0], pose[:, 2, 2] = np.cos(a), np.sin(a), -np.sin(a), np.cos(a)
+        pose[:, 0, 3], pose[:, 2, 3] = 0.3 * (t[s:s + F] - t[s]) * (1 + 0.1 * k), 1.1 * (t[s:s + F] - t[s]) * (1 + 0.1 * k)
+        ray = G.camera_pose_to_raymap(pose.astype(np.float32), np.tile(K * np.array([[8], [8], [1.0]]), (F, 1, 1)), H=H * 8, W=W * 8)
+        disp = np.stack([(0.3 + 0.25 * np.sin(0.3 * xx + 0.2 * (s + f)) * np.cos(0.2 * yy)) * (1 + 0.15 * k) for f in range(F)]).astype(np.float32)
+        rgb = np.stack([np.stack([(xx * 3 + yy * 5 + (s + f) * 7 + c) %% 17 / 17.0 for c in range(3)], -1) for f in range(F)]).astype(np.float32)
+        return SimpleNamespace(rgb=rgb, disparity=disp, raymap=ray.astype(np.float32))
+    merged = run_windows_merged(call, starts, height=H * 8, width=W * 8, smooth_camera=True, smooth_method="kalman")
+    res = run_windows(call, starts)
+    if dist.get_rank() == 0:
+        assert merged is not None and len(res) == 8 and [r.start for r in res] == starts
+        serial = blend_and_merge_window_results([SimpleNamespace(start=s, **vars(call(s))) for s in starts], height=H * 8, width=W * 8, smooth_camera=True,
+                                                smooth_method="kalman", device="cpu")
+        for a, b, what in zip(merged, serial, ("rgb", "disparity", "poses", "pointmaps")):
+            assert a.shape[0] == total and np.array_equal(a, b), what
+        open(%(out)r, "w").write("ok")
+    else:
+        assert merged is None and res is None
+    dist.barrier(); dist.destroy_process_group()
+''')
+
+
+def test_gloo_eight_ranks_eight_windows_one_round(tmp_path):
+    """The N = 8 configuration of BASELINE configs[4] — 8 windows on 8 ranks, ONE round, one gather of eight payloads, rank 0 merging all eight —
+    over gloo: bit-identical to the serial merge of the same windows (default Kalman smoothing)."""
+    out = str(tmp_path / "eight.ok")
+    script = tmp_path / "eight_worker.py"
+    script.write_text(_EIGHT_WORKER % dict(root=ROOT, out=out))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1", "--master-port", "29523", str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and os.path.exists(out), r.stderr[-3000:]

@@ -283,7 +283,7 @@ def stage_windows3(dit):
     (D:613-631: fresh generator, same seed) of the fp32 oracle — transformer AND VAE executed by torch on this device (fp32 GEMMs / fp32 convolutions,
     explicit fp32 attention), 4 steps (the reference default, P:257-261) — and the three outputs are merged by the host merge, which the REFERENCE's own
     blend pins at this geometry (tests/golden/blend_fullsize.npz), with the CLI's default Kalman smoothing (D:173-179).  Stored: per-window final latents
-    (exact bf16 bits), the merged rgb / disparity / point maps on a pixel lattice, all 72 poses, the fitted disparity scales."""
+    (exact bf16 bits, every 2nd latent pixel), the merged rgb / disparity / point maps on a pixel lattice, all 72 poses, the fitted disparity scales."""
     from aether_amd import geometry as G
     from aether_amd.scheduler import CogVideoXDPMScheduler
     from aether_amd.windows import WindowResult, blend_and_merge_window_results
@@ -321,10 +321,10 @@ def stage_windows3(dit):
     meta = dict(task="reconstruction, sliding windows", starts=starts, total_frames=total, steps=fc.WINDOWS3_STEPS, seed=fc.CLIP_SEED, window_seconds=secs,
                 seconds_total=time.perf_counter() - t0, torch=torch.__version__, video_sum=float(video.astype(np.float64).sum()),
                 generated_on=f"fp32 oracle transformer + fp32 oracle VAE with torch on {_devname()} (tools/make_fullsize_golden_gpu.py windows3); host merge, kalman smoothing")
-    np.savez_compressed(os.path.join(OUT, "fullsize_windows3.npz"), final_latents_bits=np.stack(finals), rgb_s8=m_rgb[:, ::s, ::s].astype(np.float16),
-                        disparity_s8=m_disp[:, ::s, ::s].astype(np.float32), pointmaps_s8=m_pm[:, ::s, ::s].astype(np.float32), poses=m_poses, scales=np.array(scales),
-                        window_raymaps=np.stack([w.raymap for w in wins]).astype(np.float32), window_disparity_s8=np.stack([w.disparity[:, ::s, ::s] for w in wins]),
-                        meta=json.dumps(meta))
+    # per-window final latents on every 2nd latent pixel (exact bf16 bits), merged arrays on a pixel lattice: rgb / disparity every 8th, point maps every 16th
+    np.savez_compressed(os.path.join(OUT, "fullsize_windows3.npz"), final_latents_s2_bits=np.stack(finals)[..., ::2, ::2], rgb_s8=m_rgb[:, ::s, ::s].astype(np.float16),
+                        disparity_s8=m_disp[:, ::s, ::s].astype(np.float32), pointmaps_s16=m_pm[:, ::2 * s, ::2 * s].astype(np.float32), poses=m_poses,
+                        scales=np.array(scales), meta=json.dumps(meta))
     log(f"windows3: scales {scales}; wrote gpurun_out/fixtures/fullsize_windows3.npz in {meta['seconds_total']:.0f} s")
 
 

@@ -304,9 +304,11 @@ class AetherVAE:
             if n == 0:
                 raise RuntimeError("aether_vae_workspace_bytes: " + self._lib.aether_last_error().decode())
             need = max(need, int(n))
-        need += 8 << 20                        # the tap-offset tables of the other direction / geometries (see _run_c_plan)
+        # each query counts the tap-offset tables already generated in this workspace plus those of ITS direction: the slack (added only when the
+        # workspace is (re)allocated, never to the comparison) covers the tables of the other direction and of further geometries
         if self._workspace is not None and self._workspace.numel() >= need:
             return self._workspace.numel()
+        need += 8 << 20
         if self._graphs:
             import warnings
             warnings.warn(f"AetherVAE: workspace grows to {need / 2**30:.1f} GiB; {len(self._graphs)} captured hipGraph(s) dropped", stacklevel=2)

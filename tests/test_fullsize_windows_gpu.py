@@ -20,8 +20,11 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 import fullsize_cases as fc  # noqa: E402
 
-# measured on MI355X: see the print below; {} until the first run fills them in
-BOUNDS = dict(win_lat_rel=1.4e-2, scale_rel=2e-2, disp_rel=6e-2, psnr=34.0, pm_rel=0.2, pose_t=0.2, pose_r_deg=5.0)
+# measured on MI355X (profiles/r06_parity_fullsize.log): per-window final latents 1.060e-2 / 1.059e-2 / 1.059e-2 (the 4-step bound of the single-clip test: 1.32e-2);
+# fitted scales 0.66318 / 0.45685 against the oracle's 0.66347 / 0.45691 (4.5e-4); merged disparity 2.07e-2; rgb 40.2 dB; point maps (disparity >= 0.1) 3.88e-2; camera
+# translation 2.3e-3 of the trajectory's extent, rotation 1.08 degrees (seeded random weights: the "cameras" are whatever the raymap channels of the latents decode to — the
+# similarity fit on 17 / 34 of them amplifies the per-window latent error).  Bounds 1.3 x measured (PSNR: - 2 dB).
+BOUNDS = dict(win_lat_rel=1.32e-2, scale_rel=5.8e-4, disp_rel=2.7e-2, psnr=38.2, pm_rel=5.05e-2, pose_t=3.0e-3, pose_r_deg=1.41)
 
 
 def test_three_windows_merged_against_the_oracle(cuda, fullsize_modules):
@@ -68,7 +71,10 @@ def test_three_windows_merged_against_the_oracle(cuda, fullsize_modules):
     sc_err = np.abs(np.array(scales) / z["scales"] - 1).max()
     m_disp = fc.metrics(torch.from_numpy(disp[:, ::s, ::s]), torch.from_numpy(z["disparity_s8"].astype(np.float64)))
     p_rgb = fc.psnr(torch.from_numpy(rgb[:, ::s, ::s]), torch.from_numpy(z["rgb_s8"].astype(np.float64)))
-    m_pm = fc.metrics(torch.from_numpy(pm[:, ::2 * s, ::2 * s]), torch.from_numpy(z["pointmaps_s16"].astype(np.float64)))
+    # point maps = camera ray x 1 / disparity: where the disparity is near zero the depth is 1e8 and means nothing; compared where the oracle's merged disparity >= 0.1
+    # (the mask the reference's own scale fit uses, D:292-297)
+    near = z["disparity_s8"][:, ::2, ::2] >= 0.1
+    m_pm = fc.metrics(torch.from_numpy(pm[:, ::2 * s, ::2 * s][near]), torch.from_numpy(z["pointmaps_s16"].astype(np.float64)[near]))
     ref_p = z["poses"]
     span = np.linalg.norm(ref_p[:, :3, 3].max(0) - ref_p[:, :3, 3].min(0))
     pose_t = np.linalg.norm(poses[:, :3, 3] - ref_p[:, :3, 3], axis=1).max() / max(span, 1e-9)

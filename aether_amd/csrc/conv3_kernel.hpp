@@ -16,7 +16,6 @@
 //
 // LDS: two A buffers (one per (dt,dh,cb) step) + two W buffers (one per K tile).  Instantiations:
 //     <2,4,4,2>  256x256   (Cout % 256 == 0)     2*40 + 2*32 = 144 KiB
-//     <4,2,3,2>  384x128   (Cout % 128 == 0; rounds 2-5)     2*56 + 2*16 = 144 KiB
 //     <4,2,4,2,W1>  512x128  (Cout % 128 == 0; round 6)      2*72 + 1*16 = 160 KiB — every byte of a CU's LDS
 //     <8,1,2,1>  512x32    (conv_out: 3 output channels padded to 32; round 5)   2*72 + 2*4 = 152 KiB
 //
@@ -246,6 +245,18 @@ __global__ __launch_bounds__(512) void conv3_gemm_kernel(GemmArgs p) {
     }
 
     // ---- epilogue: rows of the padded enumeration -> compact [NB, oT, oH, oW, Cout]; padding rows are dropped ----------------
+    if constexpr (NT == 2) {
+        // LDS-staged (gemm_kernel.hpp: staged_epilogue_wave): whole cache lines for the residual and the output
+        static_assert(8 * MT * 32 * 128 <= 2 * A_BUF + W_BUFS * W_TILE, "staging regions fit the (dead) operand buffers");
+        const int M = p.M, iW = p.iW, oH = p.oH, oW = p.oW;
+        staged_epilogue_wave<MT, EPI>(p, acc, m0 + wm * MT * 32, n0 + wn * NT * 32, smem + wave_s * (MT * 32 * 128), lane,
+                                      [M, plane, iW, oH, oW](int m) -> int {
+                                          const int f = m / plane, rr = m - f * plane;
+                                          const int hp = rr / iW, wp = rr - hp * iW;
+                                          return (m < M && hp < oH && wp < oW) ? (f * oH + hp) * oW + wp : -1;
+                                      });
+    } else {
+    // register-path epilogue (NT = 1: conv_out's 32-column tile)
     // acc[mt][nt][r] = C[m][n], m = m0 + (wm*MT + mt)*32 + l32,  n = n0 + (wn*NT + nt)*32 + 8*(r>>2) + 4*hi + (r&3)
     // operands fetched in batches before use (see gemm_kernel.hpp): the bias of the wave's column groups once, the residual rows of a
     // 32-row block together
@@ -322,6 +333,7 @@ __global__ __launch_bounds__(512) void conv3_gemm_kernel(GemmArgs p) {
                 }
             }
         }
+    }
     }
 }
 

@@ -97,6 +97,7 @@ extern "C" int aether_gemm_bf16(const void* A, int lda, const void* W, int ldw, 
     p.tiles_n = (N + 255) / 256;
     p.a_bytes = (unsigned)(((size_t)(M - 1) * lda + K) * 2);
     p.w_bytes = (unsigned)(((size_t)(N - 1) * ldw + K) * 2);
+    if (R) { const size_t rb = ((size_t)(M - 1) * ldr + N) * 2; if (rb >= (1ull << 32)) return aether_set_error(AETHER_ERR_SHAPE, "gemm: residual exceeds the 4 GiB a buffer descriptor can address"); p.r_bytes = (unsigned)rb; }
     dim3 block(512);
     hipStream_t s = (hipStream_t)stream;
     const bool wide = (flags & AETHER_GEMM_WIDE_STORE) != 0;

@@ -48,6 +48,7 @@ struct GemmArgs {
     int tile_base, ntile_launch;
     int part_tiled;             // split-K partials stored tile-major [slice][tile - tile_base][BM][BN] instead of [slice][M][N]
     unsigned a_bytes, w_bytes;  // extents of A and W in bytes (< 4 GiB): bounds of the buffer descriptors the LDS-DMA goes through
+    unsigned r_bytes;           // extent of R in bytes (< 4 GiB): the staged epilogue fetches the residual by LDS-DMA through a buffer descriptor
 };
 
 constexpr int GEMM_BK = 64;
@@ -172,6 +173,110 @@ AE_DEV void gemm_epilogue(const GemmArgs& p, const f32x16 (&acc)[MT][NT], int m0
                 }
             }
         }
+    }
+}
+
+// ---- LDS-staged epilogue of one WAVE tile (MT*32 rows x 64 columns), round 6 -------------------------------------------------------------
+// The register-path epilogue above moves every operand in the MFMA accumulator layout: a lane owns 4 consecutive columns of one row, so one
+// wave-instruction touches 32 rows x 16 B (stores after the half-wave exchange) or 32 rows x 8 B (residual loads) — 32 cache lines for 512 / 256
+// useful bytes.  Per-shape traces of the VAE (profiles/r06_vae_by_grid_*_before.md) price that: the SAME convolution launch costs 13 % (128-wide)
+// to 26 % (256-wide) more with a residual than without, six times what the residual's bytes cost at HBM speed.
+// Here the wave tile goes through a wave-PRIVATE 16-KiB LDS region (the operand buffers are dead once the K loop has passed its last barrier;
+// no workgroup barrier inside the epilogue):
+//   1. residual rows -> LDS by LDS-DMA, 8 rows x 128 contiguous bytes per wave-instruction (whole cache lines);
+//   2. each lane reads its residual values from LDS (ds_read_b64), finishes v = epi(acc) in fp32 exactly as the register path does, rounds ONCE
+//      to bf16 and writes the result over the residual it has just consumed (same address, same lane);
+//   3. the region is read back row-wise (ds_read_b128) and stored 8 rows x 128 contiguous bytes per wave-instruction.
+// LDS position of the 8-byte chunk c (columns 4c..4c+3) of wave-tile row r:  r*128 + ((c ^ 2*((r >> 1) & 7)) * 8): the XOR keeps a 16-byte
+// slot = two column-adjacent chunks in order (so steps 1 and 3 move contiguous global bytes) and spreads the accumulator-layout accesses of
+// step 2 over the banks (2-way conflicts instead of 32-way).
+// RowMap: m (row of the launch's enumeration) -> output row index (int), or -1 if the row is not stored (beyond M / a padding row of the tap-reuse
+// enumeration).  Bit-identical to the register path (same fp32 expression, same single rounding).
+template <int MT, int EPI, class RowMap>
+AE_DEV void staged_epilogue_wave(const GemmArgs& p, const f32x16 (&acc)[MT][2], int m0w, int n0w, char* lds_w, int lane, RowMap rowmap) {
+    constexpr int NT = 2;
+    const int hi = lane >> 5, l32 = lane & 31;
+    const bool has_bias = p.bias != nullptr;
+    const bool has_gate = (EPI == EPI_BIAS_GATE_RES) && p.gate_vid != nullptr;
+    const bool has_res = (EPI == EPI_BIAS_GATE_RES) && p.R != nullptr;
+    // rows this lane moves in steps 1 and 3: r = i*8 + (lane >> 3), i < MT*4; its 16-byte slot holds columns ccol(i) .. ccol(i) + 7
+    const int srow = lane >> 3, slot2 = 2 * (lane & 7);
+    int orow[MT * 4];                                         // output row index, -1 = not stored
+    auto ccol = [&](int i) { return n0w + 4 * (slot2 ^ (2 * (((i * 8 + srow) >> 1) & 7))); };
+#pragma unroll
+    for (int i = 0; i < MT * 4; ++i) {
+        orow[i] = rowmap(m0w + i * 8 + srow);
+        if (ccol(i) >= p.N) orow[i] = -1;                     // N % 32 == 0: an 8-column slot is all in or all out
+    }
+    if (has_res) {
+        const buf_rsrc_t r_rsrc = make_buf_rsrc(p.R, p.r_bytes);
+#pragma unroll
+        for (int i = 0; i < MT * 4; ++i) {
+            const unsigned voff = orow[i] >= 0 ? (unsigned)(((size_t)orow[i] * p.ldr + ccol(i)) * 2) : 0u;   // dropped rows fetch row 0 and are never stored
+            bglds16(r_rsrc, voff, 0u, lds_w + i * 1024);
+        }
+    }
+    int ncol[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) ncol[nt] = (n0w + nt * 32 < p.N) ? n0w + nt * 32 : 0;
+    f32x4 bv[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bv[nt][g] = has_bias ? *(const f32x4*)(p.bias + ncol[nt] + 8 * g + 4 * hi) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (has_res) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the residual tile has landed (the bias with it: needed next anyway)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int r = mt * 32 + l32;
+        const int swz = 2 * ((r >> 1) & 7);
+        char* rowp = lds_w + r * 128;
+        const float* gate = nullptr;
+        if (has_gate) {
+            const int m = min(m0w + r, p.M - 1);
+            const int b = m / p.rows_per_batch;
+            const int t = m - b * p.rows_per_batch;
+            gate = (t < p.n_text ? p.gate_txt : p.gate_vid) + (size_t)b * p.gate_bstride;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x4 gv[4];
+            u16x4 rv[4];
+            if (has_gate) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gv[g] = *(const f32x4*)(gate + ncol[nt] + 8 * g + 4 * hi);
+            }
+            if (has_res) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) rv[g] = *(const u16x4*)(rowp + (((nt * 8 + 2 * g + hi) ^ swz) << 3));
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = acc[mt][nt][4 * g + c] + bv[nt][g][c];
+                if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = gelu_tanh(v[c]);
+                }
+                if (EPI == EPI_BIAS_GATE_RES) {
+                    if (has_gate) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] *= gv[g][c];
+                    }
+                    if (has_res) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] += bf16_bits_to_f32(rv[g][c]);
+                    }
+                }
+                *(uint2*)(rowp + (((nt * 8 + 2 * g + hi) ^ swz) << 3)) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's LDS writes are done before it reads the rows back (wave-private region)
+#pragma unroll
+    for (int i = 0; i < MT * 4; ++i) {
+        const uint4 o = *(const uint4*)(lds_w + i * 1024 + lane * 16);
+        if (orow[i] >= 0) *(uint4*)(p.C + (size_t)orow[i] * p.ldc + ccol(i)) = o;
     }
 }
 
@@ -405,7 +510,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
         }
         return;
     }
-    gemm_epilogue<WM, WN, MT, NT, EPI, WIDE_STORE>(p, acc, m0, n0, wm, wn, l32, hi);
+    if constexpr (NT == 2) {
+        // LDS-staged epilogue (wave-private 16-KiB regions over the dead operand buffers).  The K loop's last barrier is behind every wave and
+        // every LDS read / LDS-DMA of the loop was waited for before it (vmcnt(0) / lgkmcnt(0) in the last slots), so the regions are free.
+        static_assert(8 * MT * 32 * 128 <= 2 * BUF_BYTES, "staging regions fit the operand buffers");
+        const int M = p.M;
+        staged_epilogue_wave<MT, EPI>(p, acc, m0 + wm * MT * 32, n0 + wn * NT * 32, smem + wave_s * (MT * 32 * 128), lane,
+                                      [M](int m) -> int { return m < M ? m : -1; });
+    } else {
+        gemm_epilogue<WM, WN, MT, NT, EPI, WIDE_STORE>(p, acc, m0, n0, wm, wn, l32, hi);
+    }
 }
 
 }  // namespace aether

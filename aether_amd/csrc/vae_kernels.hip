@@ -215,6 +215,8 @@ extern "C" int aether_conv_gemm_bf16(const void* X, int NB, int iT, int iH, int 
     const bool wide = (flags & AETHER_GEMM_WIDE_STORE) != 0;
     p.a_bytes = (unsigned)((size_t)NB * iT * iH * iW * iC * 2);
     p.w_bytes = (unsigned)((size_t)Cout * K * 2);
+    // the staged epilogue fetches the residual through a buffer descriptor: its extent must fit 32 bits
+    if (R) { const size_t rb = ((size_t)(M - 1) * ldr + Cout) * 2; if (rb >= (1ull << 32)) return aether_set_error(AETHER_ERR_SHAPE, "gemm: residual exceeds the 4 GiB a buffer descriptor can address"); p.r_bytes = (unsigned)rb; }
     dim3 block(512);
     // Tap-reuse kernel (conv3_kernel.hpp): 3x3(x3) taps in (dt, dh, channel block, dw) order, unit stride, one-voxel zero border
     // in H and W.  Output rows enumerate the padded plane, so it pays where the border is a small share of the plane.
@@ -240,9 +242,10 @@ extern "C" int aether_conv_gemm_bf16(const void* X, int NB, int iT, int iH, int 
             else { if (wide) hipLaunchKernelGGL((conv3_gemm_kernel<WM_, WN_, MT_, NT_, EPI_BIAS, true, true>), grid, block, 0, AE_STREAM, p);            \
                    else hipLaunchKernelGGL((conv3_gemm_kernel<WM_, WN_, MT_, NT_, EPI_BIAS, false, true>), grid, block, 0, AE_STREAM, p); }               \
         } while (0)
-        static const bool tile384 = getenv("AETHER_CONV3_384") != nullptr;   // A/B only: the 384x128 tile of rounds 2-5
+        // 128-wide layers: 512x128 with ONE W buffer (round 6; the 384x128 double-buffered tile of rounds 2-5 measured 2.6-7 % slower per launch
+        // in isolation and 0-0.6 % over a whole encode / decode: profiles/r06_conv512_ab.json)
         if (Cout % 256 == 0) LAUNCH_C3(2, 4, 4, 2, 256, 256);
-        else if (Cout % 128 == 0) { if (tile384) LAUNCH_C3(4, 2, 3, 2, 384, 128); else LAUNCH_C3_W1(4, 2, 4, 2, 512, 128); }
+        else if (Cout % 128 == 0) LAUNCH_C3_W1(4, 2, 4, 2, 512, 128);
         else LAUNCH_C3(8, 1, 2, 1, 512, 32);                     // conv_out (3 -> 32 padded output channels)
 #undef LAUNCH_C3_W1
 #undef LAUNCH_C3

@@ -54,6 +54,18 @@ struct GemmArgs {
 constexpr int GEMM_BK = 64;
 constexpr int GEMM_GROUP_M = 4;
 
+// Compile-time knobs of the main loop, used ONLY by tools/probes/gemm_variants_probe.hip to build the variants of profiles/r06_gemm_energy.txt;
+// the library is built with the defaults below (one loop ships).
+#ifndef AETHER_GEMM_KSPS
+#define AETHER_GEMM_KSPS 1        // k-steps per ping-pong slot (2: half the barriers, 16 MFMAs and 12 fragment reads per slot)
+#endif
+#ifndef AETHER_GEMM_MFMA_ORDER
+#define AETHER_GEMM_MFMA_ORDER 0  // 0: mt outer / nt inner; 1: snake (one operand changes per MFMA); 2: nt outer / mt inner
+#endif
+#ifndef AETHER_GEMM_SETPRIO
+#define AETHER_GEMM_SETPRIO 1     // s_setprio 1 around the MFMA burst
+#endif
+
 // tile id -> (tile_m, tile_n): groups of GEMM_GROUP_M row tiles x all column tiles, row tile fastest inside a group
 AE_DEV void gemm_tile_coords(int wgid, int tiles_m, int tiles_n, int& tile_m, int& tile_n) {
     const int per_group = GEMM_GROUP_M * tiles_n;
@@ -427,15 +439,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
             // in the MFMA slot came straight out of the matrix pipe's time; VMEM issue of the loading wave overlaps the
             // partner's MFMAs.
             auto mma = [&]() {
-                __builtin_amdgcn_s_setprio(1);
+                if (AETHER_GEMM_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int k = 0; k < KSPS; ++k)
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[k][nt], xf[k][mt], acc[mt][nt], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
+                    for (int i = 0; i < MT * NT; ++i) {
+                        const int mt = (AETHER_GEMM_MFMA_ORDER == 2) ? i % MT : i / NT;
+                        int nt = (AETHER_GEMM_MFMA_ORDER == 2) ? i / MT : i % NT;
+                        if (AETHER_GEMM_MFMA_ORDER == 1 && (mt & 1)) nt = NT - 1 - nt;
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[k][nt], xf[k][mt], acc[mt][nt], 0, 0, 0);
+                    }
+                if (AETHER_GEMM_SETPRIO) __builtin_amdgcn_s_setprio(0);
             };
             auto slot_end = [&]() {
                 __builtin_amdgcn_s_barrier();
@@ -484,7 +498,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs p) {
                 mma();                                             // last compute slot of the last tile
             }
         };
-        pingpong(std::integral_constant<int, 1>{});
+        pingpong(std::integral_constant<int, AETHER_GEMM_KSPS>{});
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------------------

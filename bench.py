@@ -476,7 +476,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # one process per GPU: re-launch this script under torch.distributed.run (the driver does this itself for N > 1)
         import socket
-        if torch.cuda.device_count() < args.gpus:
+        if torch.cuda.device_count() < args.gpus and os.environ.get("AETHER_BENCH_ONE_DEVICE") != "1":
             raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} HIP device(s) visible")
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))

@@ -14,7 +14,9 @@ for dname, data in (("random N(0,1)", torch.randn(32 * 64 * 8, device=dev).bfloa
     for shape, sname, nw, mfma_per_it, flop in ((0, "32x32x16, 128x128 tile, 1 wave/SIMD", 4, 32, 32768), (1, "16x16x32, 128x128 tile, 1 wave/SIMD", 4, 128, 16384),
                                                (2, "32x32x16, 128x64 tile, 2 waves/SIMD", 8, 16, 32768),
                                                (3, "32x32x16, 128x128 tile, snake order (one operand changes per MFMA)", 4, 32, 32768),
-                                               (4, "32x32x16, 128x128 tile, the same operand pair for every MFMA", 4, 32, 32768)):
+                                               (4, "32x32x16, 128x128 tile, the same operand pair for every MFMA", 4, 32, 32768),
+                                               (5, "32x32x16, 128x128 tile, throttled: s_sleep 6 per 32 MFMAs", 4, 32, 32768),
+                                               (6, "32x32x16, 128x128 tile, throttled: s_sleep 4 per 32 MFMAs", 4, 32, 32768)):
         iters = 40000 if shape != 1 else 10000
         iters = iters if shape != 2 else 40000
         for _ in range(2):

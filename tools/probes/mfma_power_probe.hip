@@ -42,7 +42,10 @@ __global__ __launch_bounds__(SHAPE == 2 ? 512 : 256) void mfma_probe(const bf16x
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) keep += acc[i][j][0] + acc[i][j][7];
-    } else if (SHAPE == 0) {                // 32x32x16, 4x4 accumulator tiles (128x128 per wave): 16 MFMAs per k-step of 16
+    } else if (SHAPE == 0 || SHAPE == 5 || SHAPE == 6) {   // 32x32x16, 4x4 accumulator tiles (128x128 per wave): 16 MFMAs per k-step of 16
+                                            // 5 / 6: the same stream THROTTLED by an s_sleep per iteration (6 x 64 / 4 x 64 cycles behind 32 MFMAs = 1032 cycles) to the
+                                            // 71-79 % pipe utilisation the bare 16x16x32 stream (and a real GEMM loop) reaches: which instruction shape delivers more
+                                            // flops under the power cap at EQUAL flops per cycle?
         bf16x8 a[2][4], b[2][4];
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -62,6 +65,8 @@ __global__ __launch_bounds__(SHAPE == 2 ? 512 : 256) void mfma_probe(const bf16x
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+            if (SHAPE == 5) __builtin_amdgcn_s_sleep(6);
+            if (SHAPE == 6) __builtin_amdgcn_s_sleep(4);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -133,6 +138,8 @@ extern "C" int run_mfma_probe(int shape, int nwaves, const void* src, int iters,
     else if (shape == 1) hipLaunchKernelGGL((mfma_probe<1>), grid, block, 0, s, (const bf16x8*)src, iters, out, sink);
     else if (shape == 3) hipLaunchKernelGGL((mfma_probe<3>), grid, block, 0, s, (const bf16x8*)src, iters, out, sink);
     else if (shape == 4) hipLaunchKernelGGL((mfma_probe<4>), grid, block, 0, s, (const bf16x8*)src, iters, out, sink);
+    else if (shape == 5) hipLaunchKernelGGL((mfma_probe<5>), grid, block, 0, s, (const bf16x8*)src, iters, out, sink);
+    else if (shape == 6) hipLaunchKernelGGL((mfma_probe<6>), grid, block, 0, s, (const bf16x8*)src, iters, out, sink);
     else hipLaunchKernelGGL((mfma_probe<2>), grid, block, 0, s, (const bf16x8*)src, iters, out, sink);
     return (int)hipGetLastError();
 }

@@ -96,3 +96,10 @@ AE_DEV int xcd_remap(int bid, int nwg) {
 }
 
 }  // namespace aether
+
+// dynamic LDS of aether_im2col_first (three source rows of every (dt, dh) tap + the K-offset table): shared by the kernel's entry point and the
+// VAE launch plan, which refuses an over-wide untiled first layer when the workspace is sized, not in the middle of a run
+constexpr size_t AETHER_IM2COL_LDS_LIMIT = 160 * 1024;
+inline size_t aether_im2col_first_lds_bytes(int Cin, int W, int Kpad) {
+    return ((((size_t)9 * Cin * (W + 2)) + 7) & ~(size_t)7) * 2 + (size_t)Kpad * 4;
+}

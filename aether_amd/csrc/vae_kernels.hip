@@ -290,8 +290,18 @@ extern "C" int aether_im2col_first(const void* x, long sC, long sT, long sH, lon
     if (Kpad % 64 != 0 || Kpad < 27 * Cin) return aether_set_error(AETHER_ERR_SHAPE, "im2col_first: Kpad must be a multiple of 64 >= 27*Cin");
     if (!first_chunk && t0 < 2) return aether_set_error(AETHER_ERR_ARG, "im2col_first: later chunks need two preceding frames");
     Im2colArgs p{(const unsigned short*)x, sC, sT, sH, sW, Cin, t0, first_chunk, y0, x0, T, H, W, (unsigned short*)A, Kpad};
-    const size_t lds = ((((size_t)9 * Cin * (W + 2)) + 7) & ~(size_t)7) * 2 + (size_t)Kpad * 4;
-    if (lds > 64 * 1024) return aether_set_error(AETHER_ERR_SHAPE, "im2col_first: 9 * Cin * (W + 2) source elements must fit 64 KiB of LDS");
+    const size_t lds = aether_im2col_first_lds_bytes(Cin, W, Kpad);
+    if (lds > AETHER_IM2COL_LDS_LIMIT)
+        return aether_set_error(AETHER_ERR_SHAPE, "im2col_first: 9 * Cin * (W + 2) source elements must fit 160 KiB of LDS (the launch plan reports this at "
+                                                  "aether_vae_workspace_bytes time)");
+    if (lds > 64 * 1024) {                                         // above the default dynamic-LDS limit: raise it for this kernel (a CU has 160 KiB)
+        static bool raised = false;
+        if (!raised) {
+            if (hipFuncSetAttribute((const void*)im2col_first_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AETHER_IM2COL_LDS_LIMIT) != hipSuccess)
+                return aether_set_error(AETHER_ERR_LAUNCH, "im2col_first: could not raise the dynamic LDS limit");
+            raised = true;
+        }
+    }
     hipLaunchKernelGGL(im2col_first_kernel, dim3(T * H), dim3(256), lds, AE_STREAM, p);
     return aether_check_launch("im2col_first");
 }

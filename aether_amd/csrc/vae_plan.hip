@@ -363,6 +363,8 @@ struct Plan {
                  bool first) {
         const size_t per = (size_t)T * H * W * cw.kcols * 2;
         char* A = alloc(per * NB);
+        if (aether_im2col_first_lds_bytes(Cin, W, cw.kcols) > AETHER_IM2COL_LDS_LIMIT)      // checked in the dry walk too: aether_vae_workspace_bytes reports it
+            fail(AETHER_ERR_SHAPE, "vae: first layer: 9 * Cin * (W + 2) source elements exceed 160 KiB of LDS (enable tiling for inputs this wide)");
         if (dry || rc) return A;
         for (int i = 0; i < NB; ++i)
             if (!ok(aether_im2col_first(src, sC, sT, sH, sW, Cin, t0, first ? 1 : 0, crops[i][0], crops[i][1], T, H, W, A + per * i, cw.kcols, stream),
@@ -478,7 +480,7 @@ struct Plan {
         // are per batch item, a convolution row depends on its own voxels only)
         const int NL = (nrow * ncol > 1) ? n_lanes : 1;
         const bool two_lanes = NL > 1;
-        const size_t gmax = 4;
+        const size_t gmax = 4;     // re-measured in round 6 with the staged epilogue: 4 -> 0.1815 / 0.3667 s, 3 (lanes balanced 53 / 47) -> 0.195 / 0.388, 2 -> 0.187 / 0.378
         struct Group { int th, tw; std::vector<int> idx; int lane = 0; };
         std::vector<Group> groups;
         for (int i = 0; i < nrow; ++i)

@@ -433,7 +433,8 @@ class AetherV1PipelineCogVideoX(_PipelineBase):
         reconstruction clip.  With a two-rank group BOTH ranks make every call with identical inputs and equally seeded generators — the
         encode and the sampling loop run replicated, so the latents are bit-identical on both — then rank 0 decodes the rgb latents, rank 1
         the disparity latents, and one all-gather (85 MB of bf16 per rank at 41 x 480 x 720) gives both ranks both videos.  Same kernels on
-        the same latents: outputs are bit-identical to the one-rank call.  Unlike `enable_cfg_parallel` this changes reconstruction calls
+        the same latents (the final latents are broadcast from the pair's first rank before the split, so the rgb / disparity / raymap triple is
+        consistent even if the ranks were seeded differently): outputs are bit-identical to the one-rank call.  Unlike `enable_cfg_parallel` this changes reconstruction calls
         too, so a call made by one rank only would wait for its peer forever."""
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()):
@@ -570,6 +571,15 @@ class AetherV1PipelineCogVideoX(_PipelineBase):
         self._current_timestep = None
         self._final_latents = latents             # extension: what the loop ended on (parity tests compare it; P:921)
 
+        if self._dec_group is not None and not split:
+            # decode-parallel: both ranks must decode the SAME latents.  Replicated calls with equal seeds give that by construction; a caller that
+            # passed generator=None or different seeds would otherwise get rgb from one trajectory and disparity from another, silently.  One
+            # broadcast of the final latents from the pair's first rank (6.7 MB of bf16 at 41 x 480 x 720, against the 85 MB all-gather of the
+            # decoded clips) makes the triple consistent whatever the ranks drew; with equal seeds it moves the bits the peer already has.
+            import torch.distributed as dist
+            latents = latents.contiguous()
+            dist.broadcast(latents, src=dist.get_global_rank(self._dec_group, 0), group=self._dec_group)
+            self._final_latents = latents
         nz = self.vae.config.latent_channels
         rgb_latents, disparity_latents, camera_latents = latents[:, :, :nz], latents[:, :, nz:2 * nz], latents[:, :, 2 * nz:]
         if split:

@@ -168,6 +168,31 @@ def test_im2col_first_matches_unfold(cuda, hip_lib):
         assert float(A[0, :, 81:].abs().max()) == 0
 
 
+def test_im2col_first_wide_untiled_row(cuda, hip_lib):
+    """An untiled 1 400-pixel-wide first layer (a 1080p-class encode with tiling off): 9 * 3 * 1 402 source elements = 76 KiB of LDS, above the 64-KiB default
+    of a dynamic allocation (round 5 refused it at run time; the entry point now raises the kernel's limit to the CU's 160 KiB) — and one that exceeds even that
+    is refused when the plan's workspace is SIZED, not in the middle of a run."""
+    from aether_amd import _lib
+    from aether_amd.vae import _Conv
+    g = torch.Generator().manual_seed(5)
+    Cc, T, H, W = 3, 2, 3, 1400
+    x = torch.randn(Cc, T, H, W, generator=g).to(torch.bfloat16)
+    w = torch.randn(32, Cc, 3, 3, 3, generator=g).to(torch.bfloat16)
+    conv = _Conv(w, torch.zeros(32), cuda, pad_k_to=128)
+    vae = _vae(cuda)
+    A = vae._im2col(x.to(cuda), conv, [(0, 0)], 0, T, H, W, True)
+    vol = torch.cat([x[:, :1].float().repeat(1, 2, 1, 1), x.float()], 1)[None]
+    ref = F.conv3d(vol, w.float(), padding=(0, 1, 1))[0].permute(1, 2, 3, 0).reshape(T * H * W, 32)
+    got = A[0].float().cpu() @ conv.w.float().cpu().t()
+    assert torch.allclose(got, ref, atol=2e-2, rtol=2e-2)
+    # wider than 160 KiB of LDS allows: the plan says so at workspace-query time
+    big = _vae(cuda).init_random_weights(0)
+    big.use_tiling = False
+    lib = _lib.load()
+    assert lib.aether_vae_workspace_bytes(big._handle, 0, 9, 16, 3200, 0) == 0 and b"160 KiB" in lib.aether_last_error()
+    assert lib.aether_vae_workspace_bytes(big._handle, 0, 9, 16, 1400, 0) > 0
+
+
 def _oracle_pair(cfg_kw, seed=0):
     from oracle.vae import OracleVAE, VaeConfig, init_random_
     cfg = VaeConfig(**cfg_kw)

@@ -160,7 +160,8 @@ int aether_conv_gemm_bf16(const void* X, int NB, int iT, int iH, int iW, int iC,
  * x is a strided [Cin, T_all, H_all, W_all] tensor (element strides sC,sT,sH,sW); the crop starts at frame t0,
  * row y0, column x0 and spans T x H x W; zero padding at the crop border; causal front = the two frames before t0
  * (first_chunk != 0: the crop's first frame replicated).  A bf16 [T*H*W, Kpad], column ((dt*3+dh)*3+dw)*Cin + c.
- * One workgroup per output row stages the 9*Cin source rows in LDS: 9*Cin*(W+2) elements must fit 64 KiB (AETHER_ERR_SHAPE otherwise). */
+ * One workgroup per output row stages the 9*Cin source rows in LDS: 9*Cin*(W+2) elements (+ the K-offset table) must fit the CU's 160 KiB
+ * (AETHER_ERR_SHAPE otherwise; the VAE launch plan reports such a geometry already from aether_vae_workspace_bytes). */
 int aether_im2col_first(const void* x, long sC, long sT, long sH, long sW, int Cin, int t0, int first_chunk, int y0, int x0,
                         int T, int H, int W, void* A, int Kpad, void* stream);
 

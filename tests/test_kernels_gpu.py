@@ -91,6 +91,30 @@ def test_gemm_gate_residual_inplace(cuda, hip_lib, flags):
     _bf16_close(x, ref, "gemm+gate+res")
 
 
+def test_gemm_residual_and_output_as_column_slices(cuda, hip_lib):
+    """The LDS-staged epilogue (round 6) moves the residual and the output as whole 128-byte row segments computed from `ldr` / `ldc`: R and C
+    as column slices of WIDER buffers (row strides 1 280 and 896 for N = 512), a ragged last row tile (M = 300) and a last column tile that is only
+    half inside N (N = 384 with 256-wide tiles); what lies outside the slices must stay untouched."""
+    from aether_amd import ops
+    g = torch.Generator().manual_seed(8)
+    for (M, N, K) in ((300, 512, 192), (700, 384, 128)):
+        A = torch.randn(M, K, generator=g).to(torch.bfloat16)
+        W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+        bias = torch.randn(N, generator=g)
+        Rwide = torch.randn(M, N + 768, generator=g).to(torch.bfloat16)
+        Cwide = torch.full((M, N + 384), 7.0).to(torch.bfloat16)
+        gate = torch.randn(1, 2 * N, generator=g)
+        ref = Rwide[:, 256:256 + N].float() + gate[:, :N] * (A.float() @ W.float().t() + bias)
+        Cd, Rd, gd = Cwide.to(cuda), Rwide.to(cuda), gate.to(cuda)
+        out = Cd[:, 128:128 + N]
+        ops.gemm_bf16(A.to(cuda), W.to(cuda), bias.to(cuda), ops.AETHER_EPI_BIAS_GATE_RES, R=Rd[:, 256:256 + N], gate_vid=gd[:, :N], gate_txt=gd[:, N:],
+                      rows_per_batch=M, n_text=0, out=out, flags=1)
+        torch.cuda.synchronize()
+        _bf16_close(out, ref, f"gemm+gate+res on slices {M}x{N}x{K}")
+        assert torch.equal(Cd[:, :128].cpu(), Cwide[:, :128]) and torch.equal(Cd[:, 128 + N:].cpu(), Cwide[:, 128 + N:]), "the epilogue wrote outside its column slice"
+        assert torch.equal(Rd.cpu(), Rwide)
+
+
 @pytest.mark.parametrize("gflags", [0, 1])
 @pytest.mark.parametrize("epi", ["bias", "gelu", "gate_res"])
 def test_gemm_tail_split_k(cuda, hip_lib, epi, gflags):

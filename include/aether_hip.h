@@ -45,7 +45,8 @@ int aether_check_device(void);
 #define AETHER_EPI_BIAS 0          /* C = A·Wᵀ + bias                                           */
 #define AETHER_EPI_BIAS_GELU 1     /* C = gelu_tanh(A·Wᵀ + bias)                                 */
 #define AETHER_EPI_BIAS_GATE_RES 2 /* C = R + gate[b(m),type(m),:] ⊙ (A·Wᵀ + bias)               */
-#define AETHER_GEMM_WIDE_STORE 1   /* flags bit: 16-byte stores through a half-wave exchange      */
+#define AETHER_GEMM_WIDE_STORE 1   /* flags bit: 16-byte stores through a half-wave exchange (register-path epilogue: the 32-column conv_out tile;
+                                    * the 128 x 64 wave tiles store whole 128-byte rows through LDS since round 6 whatever this bit says) */
 /* Main loop (one; the lock-step, two-k-steps-per-slot, fragment-reads-in-the-compute-slot, four-wave and persistent-grid loops measured in
  * rounds 1-3 are recorded in profiles/r0*_gemm_*): "ping-pong" — the two waves that share a SIMD alternate "read fragments from LDS + issue
  * the next tile's LDS-DMA" and "issue MFMAs" slots, phase-locked by s_barrier. */

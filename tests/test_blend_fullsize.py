@@ -8,8 +8,8 @@ sums of the whole arrays, all 72 poses and the two fitted disparity scales.  The
 
 CPU: the host (numpy, float64) merge.  `-m gpu`: `run_windows_merged` — the HIP merge kernels of csrc/merge_kernels.hip (masked scale-fit
 reduction over 17 and 34 x 480 x 720 pixels, fused scale + cross-fade, back-projection) behind the incremental WindowMerger.
-Tolerance 1e-5 of each tensor's scale (the reference sums the scale fit in float32, the kernels in float64: ~1e-7), 1e-9 for the sums' agreement
-with their own lattice being irrelevant: sums are compared at 1e-6 relative."""
+Tolerances: 1e-5 of each tensor's scale on the pixel lattices and the point-map sums (the reference sums the scale fit in float32, the kernels in
+float64: ~1e-7), 1e-6 on the per-frame rgb / disparity sums and the fitted scales, 1e-7 on the poses."""
 import os
 import sys
 import types

@@ -1,5 +1,8 @@
 #!/bin/bash
-# Same-box A/B of the round-5 library (tools/ab/libaether_hip_r05.so, built from commit 5428a84; same C ABI) against the round-6 library:
+# Same-box A/B of the round-5 library (tools/ab/libaether_hip_r05.so, built from commit 5428a84; same C ABI) against the round-6 library.
+# Build the old library first, in the build container (the .so is git-ignored and travels with the gpurun snapshot):
+#   git worktree add /tmp/r05 5428a84 && (cd /tmp/r05 && python -m aether_amd.build --force) && mkdir -p tools/ab && cp /tmp/r05/aether_amd/csrc/libaether_hip.so tools/ab/libaether_hip_r05.so
+# Then:
 # DiT step (bench.py --no-clip --no-extra-legs) and the VAE (tools/gpu_vae_bench.py, two lanes), interleaved twice.
 OUT=gpurun_out/r06ab
 mkdir -p $OUT
